@@ -1,0 +1,274 @@
+"""Process-group lifecycle and the collective surface the sync strategies use.
+
+The reference calls ``dist.init_process_group("gloo", init_method="tcp://"+master_ip,
+world_size=nodes, rank=rank)`` and later ``destroy_process_group``
+(/root/reference/part2/2a/main.py:194-207, part2/2b/main.py:163-176,
+part3/main.py:148-161) and uses exactly four collectives: gather, scatter,
+all_reduce(SUM) and DDP's broadcast (part2/2a/main.py:101,114, part2/2b/main.py:106,
+part3/main.py:137).
+
+Two transports implement one interface, selected by where the tensors live:
+
+* ``RcclCommunicator`` - tensors in GPU memory.  A native RCCL communicator
+  (csrc/comm/rccl_comm.cpp) bootstrapped by publishing the ``ncclUniqueId`` through
+  the native TCP key-value store bound to ``--master-ip host:port``
+  (csrc/comm/tcp_store.cpp).  Collectives are enqueued on a HIP stream and never
+  block the host.
+* ``HostCommunicator`` - tensors in host memory (the CPU configuration and the
+  multi-process tests that run without a GPU): ``torch.distributed`` with gloo.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+_REDUCE_OPS = ("sum", "mean")
+
+
+def split_host_port(master_ip: str):
+    host, _, port = master_ip.rpartition(":")
+    if not host or not port.isdigit():
+        raise ValueError(f"--master-ip must be host:port, got {master_ip!r}")
+    return host, int(port)
+
+
+class Communicator:
+    """Interface; ``rank``/``world_size``/``backend`` are plain attributes."""
+
+    rank: int = 0
+    world_size: int = 1
+    backend: str = "none"
+
+    def all_reduce(self, tensor: torch.Tensor, op: str = "sum") -> None:
+        raise NotImplementedError
+
+    def all_reduce_async(self, tensor: torch.Tensor, op: str = "sum"):
+        """Start an all-reduce; returns a handle with ``wait()``."""
+        raise NotImplementedError
+
+    def gather(self, tensor: torch.Tensor, slabs: Optional[Sequence[torch.Tensor]],
+               root: int = 0) -> None:
+        """Rank ``root`` receives rank r's ``tensor`` into ``slabs[r]``."""
+        raise NotImplementedError
+
+    def scatter(self, out: torch.Tensor, chunks: Optional[Sequence[torch.Tensor]],
+                root: int = 0) -> None:
+        """Rank r receives ``chunks[r]`` of rank ``root`` into ``out``."""
+        raise NotImplementedError
+
+    def broadcast(self, tensor: torch.Tensor, root: int = 0) -> None:
+        raise NotImplementedError
+
+    def barrier(self) -> None:
+        raise NotImplementedError
+
+    def group_start(self) -> None:      # lets a transport fuse a run of calls into one launch
+        pass
+
+    def group_end(self) -> None:
+        pass
+
+    def destroy(self) -> None:
+        pass
+
+
+class _Done:
+    def wait(self) -> None:
+        return None
+
+
+class HostCommunicator(Communicator):
+    """gloo over TCP for host tensors."""
+
+    def __init__(self, master_ip: str, rank: int, world_size: int, timeout_s: float = 300.0):
+        import torch.distributed as dist
+        self._dist = dist
+        self._owns_group = not dist.is_initialized()
+        if self._owns_group:
+            if os.environ.get("TORCHELASTIC_RUN_ID") and "MASTER_ADDR" in os.environ:
+                init = "env://"
+            else:
+                init = "tcp://" + master_ip
+            dist.init_process_group("gloo", init_method=init, world_size=world_size, rank=rank,
+                                    timeout=datetime.timedelta(seconds=timeout_s))
+        self.rank = dist.get_rank()
+        self.world_size = dist.get_world_size()
+        self.backend = dist.get_backend()
+
+    def _finish(self, tensor, op):
+        if op == "mean":
+            tensor.div_(self.world_size)
+
+    def all_reduce(self, tensor, op="sum"):
+        assert op in _REDUCE_OPS
+        self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM)
+        self._finish(tensor, op)
+
+    def all_reduce_async(self, tensor, op="sum"):
+        assert op in _REDUCE_OPS
+        work = self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, async_op=True)
+        comm = self
+
+        class _Handle:
+            def wait(self_inner):
+                work.wait()
+                comm._finish(tensor, op)
+        return _Handle()
+
+    def gather(self, tensor, slabs, root=0):
+        self._dist.gather(tensor, list(slabs) if self.rank == root else None, dst=root)
+
+    def scatter(self, out, chunks, root=0):
+        self._dist.scatter(out, list(chunks) if self.rank == root else None, src=root)
+
+    def broadcast(self, tensor, root=0):
+        self._dist.broadcast(tensor, src=root)
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def destroy(self):
+        if self._owns_group and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+
+
+class RcclCommunicator(Communicator):
+    """Native RCCL communicator for device tensors.
+
+    Every call enqueues on ``stream`` (default: torch's current stream) and returns
+    immediately; ordering against compute is by stream order or by the events the
+    bucket reducer records.  ``mean`` is implemented with ``ncclAvg``.
+    """
+
+    backend = "rccl"
+
+    def __init__(self, master_ip: str, rank: int, world_size: int, device_index: int,
+                 timeout_s: float = 300.0):
+        from ..ops import native
+        self._C = native.lib()
+        self.rank = rank
+        self.world_size = world_size
+        self.device_index = device_index
+        torch.cuda.set_device(device_index)
+        uid = self._exchange_unique_id(master_ip, rank, world_size, timeout_s)
+        self._comm = self._C.RcclComm(uid, rank, world_size, device_index)
+
+    # -- bootstrap ---------------------------------------------------------------
+    def _exchange_unique_id(self, master_ip, rank, world_size, timeout_s) -> bytes:
+        """Rank 0 creates the id and publishes it; everyone else fetches it.
+
+        Stand-alone launches (one process per rank started by hand or by
+        ``launch.py``, like the reference) use the native TCP store listening on
+        ``master_ip``.  Under ``torchrun`` that port already belongs to the launcher's
+        own rendezvous store, which hands workers a client connection; the id is
+        published there instead of opening a second listener on a guessed port.
+        """
+        key = "dml_rccl_unique_id"
+        if os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true":
+            from torch.distributed import TCPStore
+            store = TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]),
+                             world_size, is_master=False,
+                             timeout=datetime.timedelta(seconds=timeout_s))
+            key += "_" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+            if rank == 0:
+                uid = self._C.rccl_unique_id()
+                store.set(key, uid)
+            else:
+                uid = bytes(store.get(key))
+            self._store = None
+            return uid
+        host, port = split_host_port(master_ip)
+        self._store = self._C.TcpStore(host, port, rank == 0, world_size, float(timeout_s))
+        if rank == 0:
+            uid = self._C.rccl_unique_id()
+            self._store.set(key, uid)
+        else:
+            uid = self._store.get(key)
+        # nobody may tear the server down before every rank has read the id
+        self._store.barrier("uid_read", rank)
+        return uid
+
+    # -- helpers -----------------------------------------------------------------
+    @staticmethod
+    def _stream(stream=None) -> int:
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return int(s.cuda_stream)
+
+    @staticmethod
+    def _dtype_code(t: torch.Tensor) -> int:
+        if t.dtype == torch.float32:
+            return 0
+        if t.dtype == torch.bfloat16:
+            return 1
+        if t.dtype == torch.int64:
+            return 2
+        if t.dtype == torch.uint8:
+            return 3
+        raise TypeError(f"unsupported dtype for RCCL: {t.dtype}")
+
+    @staticmethod
+    def _check(t: torch.Tensor):
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError("RCCL collectives need contiguous device tensors")
+
+    # -- collectives -------------------------------------------------------------
+    def all_reduce(self, tensor, op="sum", stream=None):
+        assert op in _REDUCE_OPS
+        self._check(tensor)
+        self._comm.all_reduce(tensor.data_ptr(), tensor.numel(), self._dtype_code(tensor),
+                              op == "mean", self._stream(stream))
+
+    def all_reduce_async(self, tensor, op="sum"):
+        self.all_reduce(tensor, op)      # stream-ordered: nothing for the host to wait on
+        return _Done()
+
+    def gather(self, tensor, slabs, root=0, stream=None):
+        self._check(tensor)
+        ptrs = [s.data_ptr() for s in slabs] if self.rank == root else []
+        self._comm.gather(tensor.data_ptr(), ptrs, tensor.numel(), self._dtype_code(tensor),
+                          root, self._stream(stream))
+
+    def scatter(self, out, chunks, root=0, stream=None):
+        self._check(out)
+        ptrs = [c.data_ptr() for c in chunks] if self.rank == root else []
+        self._comm.scatter(out.data_ptr(), ptrs, out.numel(), self._dtype_code(out),
+                           root, self._stream(stream))
+
+    def broadcast(self, tensor, root=0, stream=None):
+        self._check(tensor)
+        self._comm.broadcast(tensor.data_ptr(), tensor.numel(), self._dtype_code(tensor),
+                             root, self._stream(stream))
+
+    def barrier(self):
+        token = torch.zeros(1, device=f"cuda:{self.device_index}")
+        self.all_reduce(token)
+        torch.cuda.current_stream().synchronize()
+
+    def group_start(self):
+        self._comm.group_start()
+
+    def group_end(self):
+        self._comm.group_end()
+
+    @property
+    def native(self):
+        return self._comm
+
+    def destroy(self):
+        if self._comm is not None:
+            torch.cuda.synchronize()
+            self._comm.destroy()
+            self._comm = None
+        self._store = None
+
+
+def init_communicator(master_ip: str, rank: int, world_size: int, device: torch.device,
+                      timeout_s: float = 300.0) -> Communicator:
+    """Pick the transport from the device the model trains on."""
+    if device.type == "cuda":
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        return RcclCommunicator(master_ip, rank, world_size, index, timeout_s)
+    return HostCommunicator(master_ip, rank, world_size, timeout_s)

@@ -1,0 +1,55 @@
+"""Worker for the multi-process sync tests: trains a few steps on synthetic data and
+writes the final flat parameter vector (and BN buffers) of its rank to --out."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+
+import torch  # noqa: E402
+
+from distributed_machine_learning_amd.config import TrainConfig  # noqa: E402
+from distributed_machine_learning_amd.engine.trainer import Trainer  # noqa: E402
+from distributed_machine_learning_amd.parallel.comm import init_communicator  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--master-ip", default="127.0.0.1:29431")
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--num-nodes", type=int, default=1)
+    ap.add_argument("--sync", default="none")
+    ap.add_argument("--grad-reduce", default=None)
+    ap.add_argument("--batch-size", type=int, default=4)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--batch-norm", action="store_true")
+    ap.add_argument("--device", default="cpu")
+    ap.add_argument("--backend", default="torch")
+    ap.add_argument("--dtype", default="fp32")
+    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--out", required=True)
+    ns = ap.parse_args()
+    cfg = TrainConfig(master_ip=ns.master_ip, rank=ns.rank, num_nodes=ns.num_nodes, sync=ns.sync,
+                      grad_reduce=ns.grad_reduce, batch_size=ns.batch_size, iters=ns.iters,
+                      batch_norm=ns.batch_norm, device=ns.device, backend=ns.backend,
+                      dtype=ns.dtype, lr=ns.lr, train_size=256, test_size=16, summary=False,
+                      eval=False, comm_timeout_s=60.0)
+    torch.set_num_threads(2)
+    device = torch.device(ns.device if ns.device != "cuda" else
+                          f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}")
+    comm = None
+    if ns.sync != "none":
+        comm = init_communicator(cfg.master_ip, cfg.rank, cfg.num_nodes, device, 60.0)
+    torch.manual_seed(cfg.seed)
+    tr = Trainer(cfg, device, comm)
+    train_loader, _ = tr.build_loaders()
+    tr.train_epoch(train_loader, 0)
+    sd = {k: v.float().cpu() for k, v in tr.backend.state_dict().items()}
+    torch.save(sd, f"{ns.out}.rank{ns.rank}")
+    tr.close()
+    if comm is not None:
+        comm.destroy()
+
+
+if __name__ == "__main__":
+    main()

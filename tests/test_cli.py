@@ -1,0 +1,54 @@
+import re
+import subprocess
+import sys
+import os
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _run(script, *args):
+    cmd = [sys.executable, os.path.join(ROOT, script), "--device", "cpu", "--iters", "40",
+           "--batch-size", "2", "--train-size", "96", "--test-size", "8", *args]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+
+
+def test_part1_output_contract():
+    r = _run("part1/main.py")
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "Total params: 9,225,610" in out
+    assert re.search(r"^Loss at 20th batch is \d+\.\d+", out, re.M)
+    assert re.search(r"^Loss at 40th batch is \d+\.\d+", out, re.M)
+    assert re.search(r"^Total execution time is : [\d.e-]+ seconds$", out, re.M)
+    assert re.search(r"^Average execution time is  : [\d.e-]+ seconds$", out, re.M)
+    assert re.search(r"^Test set: Average loss: \d+\.\d{4}, Accuracy: \d+/8 \(\d+%\)$", out, re.M)
+    assert "master_ip" not in out          # part1 has no process group
+
+
+def test_part3_flags_and_lines():
+    r = _run("part3/main.py", "--master-ip", "127.0.0.1:29517", "--rank", "0", "--num-nodes", "1")
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "master_ip = 127.0.0.1:29517 and nodes = 1" in out
+    assert re.search(r"^\[\d+\] world_size = 1, rank = 0, backend=gloo$", out, re.M)
+    assert "Epoch 0 triggered" in out
+    assert "BatchNorm2d-2" in out
+    assert re.search(r"^Average execution time is : [\d.e-]+ seconds$", out, re.M)
+
+
+def test_reference_flag_defaults():
+    from distributed_machine_learning_amd.cli import build_parser
+    from distributed_machine_learning_amd.config import part_defaults
+    ns = build_parser(part_defaults("part2a")).parse_args([])
+    assert (ns.master_ip, ns.rank, ns.num_nodes) == ("127.0.1.1:8000", 0, 1)
+    assert ns.batch_size == 64 and ns.sync == "gather_scatter" and not ns.batch_norm
+    assert part_defaults("part3").batch_norm and part_defaults("part1").batch_size == 256
+
+
+def test_rendezvous_failure_exits_nonzero():
+    cmd = [sys.executable, os.path.join(ROOT, "part2/2b/main.py"), "--device", "cpu",
+           "--master-ip", "127.0.0.1:29518", "--rank", "1", "--num-nodes", "2",
+           "--comm-timeout", "3", "--no-summary"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode != 0
+    assert "could not join the process group" in r.stderr
