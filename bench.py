@@ -1,0 +1,149 @@
+"""Headline benchmark: VGG-11 training throughput on synthetic CIFAR-10-shaped data.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
+
+Flagship configuration = the reference's fastest variant (part3,
+/root/reference/part3/main.py): VGG-11 with BatchNorm, SGD lr 0.1 / momentum 0.9 /
+weight decay 1e-4, bucketed all-reduce (25 MB buckets, mean) overlapped with backward,
+here with 256 images per GPU (weak scaling), bf16 compute with fp32 master weights.
+The timed region is the reference's (/root/reference/part3/main.py:50-67): zero_grad,
+forward, loss, backward (+ gradient sync), optimizer step; batches are prepared before.
+Other reference configurations: ``--mode part1|part2a|part2b|part3`` and
+``--no-batch-norm``; ``--backend torch`` times stock PyTorch-ROCm on the same GPU.
+
+Rank 0 prints ONE JSON line; ``value`` is whole-job images/sec, ``vs_baseline`` divides by
+the best number the reference publishes (part3 on its 4-node CPU cluster, 305.4 images/s).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from distributed_machine_learning_amd.config import SEED, TrainConfig  # noqa: E402
+
+REFERENCE_IMAGES_PER_SEC = {"part1": 106.8, "part2a": 211.4, "part2b": 273.9, "part3": 305.4}
+MODE_SYNC = {"part1": "none", "part2a": "gather_scatter", "part2b": "all_reduce", "part3": "ddp"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=tuple(MODE_SYNC), default="part3")
+    ap.add_argument("--batch-size", type=int, default=256, help="images per GPU")
+    bn = ap.add_mutually_exclusive_group()
+    bn.add_argument("--batch-norm", dest="batch_norm", action="store_true", default=None)
+    bn.add_argument("--no-batch-norm", dest="batch_norm", action="store_false")
+    ap.add_argument("--backend", choices=("native", "torch"), default="native")
+    ap.add_argument("--dtype", choices=("bf16", "fp32"), default="bf16")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU)")
+    ap.add_argument("--bucket-cap-mb", type=float, default=25.0)
+    ap.add_argument("--serialize-streams", action="store_true")
+    ap.add_argument("--distinct-batches", type=int, default=4)
+    return ap.parse_args()
+
+
+def main():
+    ns = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != ns.gpus:
+        if world == 1 and ns.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
+                             "(one process per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {ns.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from distributed_machine_learning_amd.data import synthetic_cifar
+    from distributed_machine_learning_amd.data.transforms import BatchTransform
+    from distributed_machine_learning_amd.engine.trainer import make_backend
+    from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
+
+    batch_norm = ns.batch_norm if ns.batch_norm is not None else (ns.mode == "part3")
+    sync = MODE_SYNC[ns.mode] if world > 1 else "none"
+    master = f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{os.environ.get('MASTER_PORT', '29500')}"
+    comm = RcclCommunicator(master, rank, world, local_rank, timeout_s=120) if world > 1 else None
+
+    cfg = TrainConfig(master_ip=master, rank=rank, num_nodes=world, sync=sync,
+                      batch_size=ns.batch_size, batch_norm=batch_norm, dtype=ns.dtype,
+                      backend=ns.backend, device="cuda", use_graph=ns.graph,
+                      bucket_cap_mb=ns.bucket_cap_mb, serialize_streams=ns.serialize_streams,
+                      summary=False, eval=False)
+    torch.manual_seed(SEED)
+    backend = make_backend(cfg, device, comm)
+    backend.train_mode(True)
+
+    # synthetic CIFAR-shaped batches, rank-strided like the reference's sampler, prepared
+    # (augmented, normalised, laid out) before the clock starts
+    n_img = ns.batch_size * world * ns.distinct_batches
+    ds = synthetic_cifar(n_img, SEED).to(device)
+    tf = BatchTransform(True, backend.loader_layout, SEED)
+    batches = []
+    for i in range(ns.distinct_batches):
+        idx = torch.arange(ns.batch_size, device=device) * world + rank + i * ns.batch_size * world
+        imgs, labels = ds.take(idx)
+        batches.append((tf(imgs, idx).contiguous(), labels.contiguous()))
+
+    def barrier():
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for i in range(ns.warmup):
+        loss = backend.train_step(*batches[i % len(batches)])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(ns.steps):
+        loss = backend.train_step(*batches[i % len(batches)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if comm is not None:       # MAX over ranks
+        times = torch.zeros(world, device=device)
+        times[rank] = elapsed
+        comm.all_reduce(times, "sum")
+        torch.cuda.synchronize()
+        elapsed = float(times.max())
+    final_loss = float(loss.item()) if loss is not None else float("nan")
+
+    if rank == 0:
+        ms = elapsed / ns.steps * 1e3
+        value = ns.batch_size * world * ns.steps / elapsed
+        par = "single" if world == 1 else f"dp{world}"
+        print(json.dumps({
+            "metric": "images/sec, VGG-11 CIFAR-10-shaped training, batch 256 per GPU",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": ns.steps,
+            "warmup": ns.warmup, "ms_per_step": round(ms, 4), "s_per_iter": round(ms / 1e3, 7),
+            "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(value / REFERENCE_IMAGES_PER_SEC["part3"], 2),
+            "dtype": ns.dtype, "data": "synthetic",
+            "config": {"model": "VGG-11" + (" + BatchNorm" if batch_norm else ""),
+                       "mode": ns.mode, "sync": sync, "global_batch": ns.batch_size * world,
+                       "batch_per_gpu": ns.batch_size, "image": "3x32x32", "parallelism": par,
+                       "optimizer": "SGD lr0.1 m0.9 wd1e-4 (fused)", "backend": backend.name,
+                       "graph": bool(ns.graph), "final_loss": round(final_loss, 4),
+                       "baseline": "reference part3: 305.4 images/s on 4 CPU nodes "
+                                   "(group25.pdf p7); part1: 106.8 images/s"}}))
+    backend.close()
+    if comm is not None:
+        comm.destroy()
+
+
+if __name__ == "__main__":
+    main()

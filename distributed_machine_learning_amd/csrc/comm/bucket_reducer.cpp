@@ -1,0 +1,179 @@
+// Bucket planner, stream-overlapped bucket reducer, and the Python bindings of the
+// communication runtime.
+//
+// The reducer is the native counterpart of what DistributedDataParallel(model,
+// bucket_cap_mb=25) gives the reference (/root/reference/part3/main.py:137): gradients
+// are grouped into buckets in reverse parameter order and each bucket's all-reduce is
+// started as soon as backward has produced its last gradient, overlapping the rest of
+// backward.  Here a bucket is a slice of the flat gradient buffer, the all-reduce runs in
+// place on a dedicated HIP stream, and ordering is expressed with HIP events only.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <stdexcept>
+
+#include "dml_comm.h"
+
+namespace py = pybind11;
+
+namespace dml {
+
+std::vector<BucketRange> plan_buckets(const std::vector<size_t>& sizes_bytes, size_t cap_bytes,
+                                      size_t first_cap_bytes) {
+    std::vector<BucketRange> out;
+    int hi = (int)sizes_bytes.size();
+    size_t acc = 0;
+    size_t cap = first_cap_bytes > 0 ? first_cap_bytes : cap_bytes;
+    for (int i = (int)sizes_bytes.size() - 1; i >= 0; --i) {
+        acc += sizes_bytes[i];
+        if (acc >= cap) {
+            out.push_back({i, hi});
+            hi = i;
+            acc = 0;
+            cap = cap_bytes;
+        }
+    }
+    if (hi > 0) out.push_back({0, hi});
+    return out;
+}
+
+namespace {
+void check_hip(hipError_t e, const char* what) {
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string("HIP ") + what + " failed: " + hipGetErrorString(e));
+}
+}  // namespace
+
+BucketReducer::BucketReducer(RcclComm* comm, float* flat_grads, std::vector<Slice> slices,
+                             bool average, bool serialize)
+    : comm_(comm), grads_(flat_grads), slices_(std::move(slices)), average_(average),
+      serialize_(serialize) {
+    if (!comm_) throw std::invalid_argument("BucketReducer: communicator missing");
+    if (!serialize_)
+        check_hip(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking), "hipStreamCreate");
+    ready_.resize(slices_.size());
+    done_.resize(slices_.size());
+    launched_.assign(slices_.size(), 0);
+    for (size_t i = 0; i < slices_.size(); ++i) {
+        check_hip(hipEventCreateWithFlags(&ready_[i], hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&done_[i], hipEventDisableTiming), "hipEventCreate");
+    }
+}
+
+BucketReducer::~BucketReducer() {
+    for (auto e : ready_) (void)hipEventDestroy(e);
+    for (auto e : done_) (void)hipEventDestroy(e);
+    if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
+}
+
+void BucketReducer::begin_step() { launched_.assign(slices_.size(), 0); }
+
+void BucketReducer::bucket_ready(int b, hipStream_t compute) {
+    if (b < 0 || b >= (int)slices_.size()) throw std::out_of_range("BucketReducer: bucket index");
+    if (launched_[b]) throw std::logic_error("BucketReducer: bucket marked ready twice");
+    launched_[b] = 1;
+    const Slice& s = slices_[b];
+    if (serialize_) {       // debug mode: same stream, no overlap, no events
+        comm_->all_reduce(grads_ + s.offset, s.count, DT_F32, average_, compute);
+        return;
+    }
+    check_hip(hipEventRecord(ready_[b], compute), "hipEventRecord(ready)");
+    check_hip(hipStreamWaitEvent(comm_stream_, ready_[b], 0), "hipStreamWaitEvent(comm)");
+    comm_->all_reduce(grads_ + s.offset, s.count, DT_F32, average_, comm_stream_);
+    check_hip(hipEventRecord(done_[b], comm_stream_), "hipEventRecord(done)");
+}
+
+void BucketReducer::wait_all(hipStream_t compute) {
+    for (size_t b = 0; b < slices_.size(); ++b) {
+        if (!launched_[b])
+            throw std::logic_error("BucketReducer: backward ended with bucket " +
+                                   std::to_string(b) + " never marked ready");
+        if (!serialize_)
+            check_hip(hipStreamWaitEvent(compute, done_[b], 0), "hipStreamWaitEvent(compute)");
+    }
+}
+
+// ----------------------------------------------------------------------- bindings
+void bind_comm(py::module_& m) {
+    py::class_<TcpStore>(m, "TcpStore")
+        .def(py::init<const std::string&, int, bool, int, double>(), py::arg("host"),
+             py::arg("port"), py::arg("is_server"), py::arg("world_size"), py::arg("timeout_s"),
+             py::call_guard<py::gil_scoped_release>())
+        .def("set", [](TcpStore& s, const std::string& k, py::bytes v) {
+            std::string val = v;
+            py::gil_scoped_release rel;
+            s.set(k, val);
+        })
+        .def("get", [](TcpStore& s, const std::string& k) {
+            std::string out;
+            {
+                py::gil_scoped_release rel;
+                out = s.get(k);
+            }
+            return py::bytes(out);
+        })
+        .def("add", &TcpStore::add, py::call_guard<py::gil_scoped_release>())
+        .def("barrier", &TcpStore::barrier, py::call_guard<py::gil_scoped_release>())
+        .def_property_readonly("port", &TcpStore::port);
+
+    m.def("rccl_unique_id", []() { return py::bytes(RcclComm::unique_id()); });
+
+    py::class_<RcclComm>(m, "RcclComm")
+        .def(py::init([](py::bytes uid, int rank, int world, int device) {
+            std::string id = uid;
+            py::gil_scoped_release rel;
+            return new RcclComm(id, rank, world, device);
+        }))
+        .def_property_readonly("rank", &RcclComm::rank)
+        .def_property_readonly("world_size", &RcclComm::world_size)
+        .def("all_reduce", [](RcclComm& c, uintptr_t buf, size_t n, int dt, bool avg, uintptr_t s) {
+            c.all_reduce((void*)buf, n, (DType)dt, avg, (hipStream_t)s);
+        })
+        .def("broadcast", [](RcclComm& c, uintptr_t buf, size_t n, int dt, int root, uintptr_t s) {
+            c.broadcast((void*)buf, n, (DType)dt, root, (hipStream_t)s);
+        })
+        .def("gather", [](RcclComm& c, uintptr_t send, std::vector<uintptr_t> recv, size_t n,
+                          int dt, int root, uintptr_t s) {
+            std::vector<void*> r;
+            for (auto p : recv) r.push_back((void*)p);
+            c.gather((const void*)send, r, n, (DType)dt, root, (hipStream_t)s);
+        })
+        .def("scatter", [](RcclComm& c, uintptr_t out, std::vector<uintptr_t> chunks, size_t n,
+                           int dt, int root, uintptr_t s) {
+            std::vector<const void*> r;
+            for (auto p : chunks) r.push_back((const void*)p);
+            c.scatter((void*)out, r, n, (DType)dt, root, (hipStream_t)s);
+        })
+        .def("group_start", &RcclComm::group_start)
+        .def("group_end", &RcclComm::group_end)
+        .def("wait_stream", [](RcclComm& c, uintptr_t s, double t) {
+            py::gil_scoped_release rel;
+            c.wait_stream((hipStream_t)s, t);
+        })
+        .def("destroy", &RcclComm::destroy);
+
+    m.def("plan_buckets", [](std::vector<size_t> sizes, size_t cap, size_t first_cap) {
+        std::vector<std::pair<int, int>> out;
+        for (auto& b : plan_buckets(sizes, cap, first_cap)) out.push_back({b.lo, b.hi});
+        return out;
+    });
+
+    py::class_<BucketReducer>(m, "BucketReducer")
+        .def(py::init([](RcclComm* comm, uintptr_t grads,
+                         std::vector<std::pair<size_t, size_t>> slices, bool average,
+                         bool serialize) {
+            std::vector<BucketReducer::Slice> s;
+            for (auto& p : slices) s.push_back({p.first, p.second});
+            return new BucketReducer(comm, (float*)grads, s, average, serialize);
+        }), py::keep_alive<1, 2>())
+        .def_property_readonly("num_buckets", &BucketReducer::num_buckets)
+        .def("begin_step", &BucketReducer::begin_step)
+        .def("bucket_ready", [](BucketReducer& r, int b, uintptr_t s) {
+            r.bucket_ready(b, (hipStream_t)s);
+        })
+        .def("wait_all", [](BucketReducer& r, uintptr_t s) { r.wait_all((hipStream_t)s); })
+        .def_property_readonly("comm_stream",
+                               [](BucketReducer& r) { return (uintptr_t)r.comm_stream(); });
+}
+
+}  // namespace dml

@@ -1,0 +1,399 @@
+// VggEngine: layout planning and the per-step kernel schedule.
+//
+// Schedule of one training step (reference order, /root/reference/part1/main.py:38-46):
+//   memset(grads), memset(loss)                                     optimizer.zero_grad()
+//   conv -> [bn+relu] -> [pool] ... -> linear                       model(data)
+//   softmax cross-entropy fwd+bwd                                   criterion / backward
+//   linear bwd, then per conv layer back to front:
+//     [pool bwd] -> [bn+relu bwd] -> bias grad -> wgrad -> dgrad    loss.backward()
+//     -> reducer.bucket_ready(...) for every bucket this layer completes
+//   reducer.wait_all -> fused SGD -> weight shadow / repack          optimizer.step()
+#include "dml_engine.h"
+
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <stdexcept>
+
+#include "dml_kernels.h"
+
+namespace py = pybind11;
+
+namespace dml {
+
+namespace {
+
+constexpr size_t kAlign = 64;     // elements; keeps every slot 128/256-byte aligned
+
+size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+void check_hip(hipError_t e, const char* what) {
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string("HIP ") + what + " failed: " + hipGetErrorString(e));
+}
+
+}  // namespace
+
+VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_norm,
+                     int num_classes)
+    : max_batch_(max_batch), num_classes_(num_classes), bn_(batch_norm) {
+    if (max_batch <= 0) throw std::invalid_argument("VggEngine: batch must be positive");
+    if (num_classes < 1 || num_classes > 16)
+        throw std::invalid_argument("VggEngine: num_classes must be in [1,16]");
+    int cin = 3, hw = 32, module_index = 0;
+    size_t p = 0, b = 0;
+    for (size_t i = 0; i < widths.size(); ++i) {
+        const int w = widths[i];
+        if (w < 0) {
+            if (convs_.empty() || convs_.back().pool_after || hw < 2)
+                throw std::invalid_argument("VggEngine: misplaced pool in width table");
+            convs_.back().pool_after = true;
+            hw /= 2;
+            ++module_index;
+            continue;
+        }
+        if (w % 64) throw std::invalid_argument("VggEngine: channel widths must be multiples of 64");
+        if (convs_.empty() ? (w != 64) : (w % 128 != 0))
+            throw std::invalid_argument("VggEngine: first conv must have 64 channels, later ones a "
+                                        "multiple of 128");
+        Conv c;
+        c.cin = cin; c.cout = w; c.hw = hw; c.pool_after = false;
+        c.gamma_off = c.beta_off = c.rm_off = c.rv_off = c.save_off = 0;
+        const int layer = (int)convs_.size();
+        const std::string key = "layers." + std::to_string(module_index);
+        c.w_off = p;
+        slots_.push_back({key + ".weight", p, (size_t)w * 9 * cin, {w, 3, 3, cin}, layer});
+        p = align_up(p + (size_t)w * 9 * cin);
+        c.b_off = p;
+        slots_.push_back({key + ".bias", p, (size_t)w, {w}, layer});
+        p = align_up(p + w);
+        ++module_index;
+        if (bn_) {
+            const std::string bkey = "layers." + std::to_string(module_index);
+            c.gamma_off = p;
+            slots_.push_back({bkey + ".weight", p, (size_t)w, {w}, layer});
+            p = align_up(p + w);
+            c.beta_off = p;
+            slots_.push_back({bkey + ".bias", p, (size_t)w, {w}, layer});
+            p = align_up(p + w);
+            c.rm_off = b;
+            bn_slots_.push_back({bkey + ".running_mean", b, (size_t)w, {w}, layer});
+            b = align_up(b + w);
+            c.rv_off = b;
+            bn_slots_.push_back({bkey + ".running_var", b, (size_t)w, {w}, layer});
+            b = align_up(b + w);
+            ++module_index;
+        }
+        ++module_index;   // the ReLU
+        convs_.push_back(c);
+        cin = w;
+    }
+    if (convs_.empty()) throw std::invalid_argument("VggEngine: empty width table");
+    fc_in_ = cin * hw * hw;
+    if (hw != 1) throw std::invalid_argument("VggEngine: the feature map must be 1x1 at the classifier");
+    const int fc_layer = (int)convs_.size();
+    fcw_off_ = p;
+    slots_.push_back({"fc1.weight", p, (size_t)num_classes * fc_in_, {num_classes, fc_in_}, fc_layer});
+    p = align_up(p + (size_t)num_classes * fc_in_);
+    fcb_off_ = p;
+    slots_.push_back({"fc1.bias", p, (size_t)num_classes, {num_classes}, fc_layer});
+    p = align_up(p + num_classes);
+    param_elems_ = p;
+    bn_elems_ = b;
+
+    // ---- bf16 arena
+    size_t a = 0;
+    shadow_off_ = a; a = align_up(a + param_elems_);
+    w1_off_ = a;     a = align_up(a + 64 * 64);
+    size_t max_act = 0;
+    const size_t B = (size_t)max_batch_;
+    for (size_t i = 0; i < convs_.size(); ++i) {
+        Conv& c = convs_[i];
+        const size_t act = B * c.hw * c.hw * c.cout;
+        max_act = act > max_act ? act : max_act;
+        c.wd_off = a;
+        if (i > 0) a = align_up(a + (size_t)c.cout * 9 * c.cin);
+        c.pre_off = a;
+        if (bn_) a = align_up(a + act);
+        c.out_off = a; a = align_up(a + act);
+        c.pool_off = a;
+        if (c.pool_after) a = align_up(a + act / 4);
+    }
+    gbuf_off_[0] = a; a = align_up(a + max_act);
+    gbuf_off_[1] = a; a = align_up(a + max_act);
+    arena_elems_ = a;
+
+    // ---- fp32 workspace
+    size_t w = 0;
+    logits_off_ = w;  w = align_up(w + B * 16);
+    dlogits_off_ = w; w = align_up(w + B * 16);
+    loss_off_ = w;    w = align_up(w + 64);
+    stats_off_ = w;   w = align_up(w + 2 * 2048);
+    for (auto& c : convs_) {
+        c.save_off = w;
+        if (bn_) w = align_up(w + 2 * (size_t)c.cout);
+    }
+    slab_elems_ = 0;
+    for (size_t i = 1; i < convs_.size(); ++i) {
+        const Conv& c = convs_[i];
+        ConvShape f = {max_batch_, c.hw, c.cin, c.cout};
+        ConvShape d = {max_batch_, c.hw, c.cout, c.cin};
+        const size_t need_f = conv3x3_igemm_workspace_elems(f);
+        const size_t need_d = conv3x3_igemm_workspace_elems(d);
+        slab_elems_ = need_f > slab_elems_ ? need_f : slab_elems_;
+        slab_elems_ = need_d > slab_elems_ ? need_d : slab_elems_;
+    }
+    slab_off_ = w; w = align_up(w + slab_elems_);
+    ws_elems_ = w;
+    buckets_by_layer_.assign(convs_.size() + 1, {});
+}
+
+VggEngine::~VggEngine() {
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+}
+
+void VggEngine::bind(float* params, float* grads, float* momentum, float* bn_buffers,
+                     uint16_t* arena, float* workspace) {
+    if (!params || !grads || !momentum || !arena || !workspace || (bn_ && !bn_buffers))
+        throw std::invalid_argument("VggEngine::bind: null buffer");
+    params_ = params; grads_ = grads; mom_ = momentum; bnbuf_ = bn_buffers;
+    arena_ = arena; ws_ = workspace;
+}
+
+void VggEngine::set_reducer(BucketReducer* reducer, const std::vector<BucketRange>& buckets) {
+    reducer_ = reducer;
+    buckets_by_layer_.assign(convs_.size() + 1, {});
+    if (!reducer) return;
+    if ((int)buckets.size() != reducer->num_buckets())
+        throw std::invalid_argument("VggEngine::set_reducer: bucket count mismatch");
+    for (size_t b = 0; b < buckets.size(); ++b) {
+        const int lo = buckets[b].lo;
+        if (lo < 0 || lo >= (int)slots_.size())
+            throw std::invalid_argument("VggEngine::set_reducer: bucket range outside the slots");
+        // a bucket is complete once the layer owning its first (earliest) slot has run backward
+        buckets_by_layer_[slots_[lo].layer].push_back((int)b);
+    }
+}
+
+void VggEngine::fire_buckets(int layer, hipStream_t stream) {
+    if (!reducer_) return;
+    for (int b : buckets_by_layer_[layer]) reducer_->bucket_ready(b, stream);
+}
+
+void VggEngine::refresh_weights(hipStream_t stream) {
+    if (!params_) throw std::logic_error("VggEngine: bind() first");
+    // Full refresh: needed when the master weights were written from outside (initialisation,
+    // load_state_dict); during training the optimizer kernel keeps the shadow current.
+    cast_f32_to_bf16(params_, arena_ + shadow_off_, param_elems_, stream);
+    repack_conv1_weights(params_ + convs_[0].w_off, arena_ + w1_off_, stream);
+    for (size_t i = 1; i < convs_.size(); ++i) {
+        const Conv& c = convs_[i];
+        repack_dgrad_weights(arena_ + shadow_off_ + c.w_off, arena_ + c.wd_off, c.cout, c.cin,
+                             stream);
+    }
+}
+
+void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t stream) {
+    if (!params_) throw std::logic_error("VggEngine: bind() first");
+    if (batch <= 0 || batch > max_batch_) throw std::invalid_argument("VggEngine: bad batch size");
+    const uint16_t* in = x;
+    float* slab = ws_ + slab_off_;
+    for (size_t i = 0; i < convs_.size(); ++i) {
+        const Conv& c = convs_[i];
+        uint16_t* dst = arena_ + (bn_ ? c.pre_off : c.out_off);
+        if (i == 0) {
+            conv1_fprop(in, arena_ + w1_off_, params_ + c.b_off, dst, batch, !bn_, stream);
+        } else {
+            ConvShape s = {batch, c.hw, c.cin, c.cout};
+            conv3x3_igemm(in, arena_ + shadow_off_ + c.w_off, dst, params_ + c.b_off, nullptr, slab,
+                          slab_elems_, s, bn_ ? EPI_BIAS : EPI_BIAS_RELU, stream);
+        }
+        if (bn_) {
+            const int rows = batch * c.hw * c.hw;
+            if (training)
+                bn_relu_fwd_train(dst, arena_ + c.out_off, params_ + c.gamma_off,
+                                  params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off,
+                                  ws_ + c.save_off, ws_ + c.save_off + c.cout, ws_ + stats_off_,
+                                  rows, c.cout, 0.1f, 1e-5f, stream);
+            else
+                bn_relu_fwd_eval(dst, arena_ + c.out_off, params_ + c.gamma_off,
+                                 params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off, rows,
+                                 c.cout, 1e-5f, stream);
+        }
+        in = arena_ + c.out_off;
+        if (c.pool_after) {
+            maxpool2x2_fwd(in, arena_ + c.pool_off, batch, c.hw, c.cout, stream);
+            in = arena_ + c.pool_off;
+        }
+    }
+    linear_fwd(in, params_ + fcw_off_, params_ + fcb_off_, ws_ + logits_off_, batch, fc_in_,
+               num_classes_, stream);
+    if (training && bn_) ++bn_steps_;
+}
+
+void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hipStream_t stream) {
+    const int nconv = (int)convs_.size();
+    float* slab = ws_ + slab_off_;
+    softmax_xent(ws_ + logits_off_, target, ws_ + loss_off_, ws_ + dlogits_off_, nullptr, batch,
+                 num_classes_, 1.0f, stream);
+    const Conv& last = convs_[nconv - 1];
+    const uint16_t* fc_in = arena_ + (last.pool_after ? last.pool_off : last.out_off);
+    int cur = 0;        // index of the ping-pong buffer holding the incoming gradient
+    linear_bwd(fc_in, params_ + fcw_off_, ws_ + dlogits_off_, grads_ + fcw_off_, grads_ + fcb_off_,
+               arena_ + gbuf_off_[cur], batch, fc_in_, num_classes_, stream);
+    fire_buckets(nconv, stream);
+    for (int i = nconv - 1; i >= 0; --i) {
+        const Conv& c = convs_[i];
+        const int rows = batch * c.hw * c.hw;
+        if (c.pool_after) {
+            maxpool2x2_bwd(arena_ + c.out_off, arena_ + gbuf_off_[cur], arena_ + gbuf_off_[cur ^ 1],
+                           batch, c.hw, c.cout, /*relu_mask=*/!bn_, stream);
+            cur ^= 1;
+        }
+        if (bn_) {
+            bn_relu_bwd(arena_ + c.pre_off, arena_ + gbuf_off_[cur], arena_ + gbuf_off_[cur ^ 1],
+                        params_ + c.gamma_off, params_ + c.beta_off, ws_ + c.save_off,
+                        ws_ + c.save_off + c.cout, grads_ + c.gamma_off, grads_ + c.beta_off,
+                        ws_ + stats_off_, rows, c.cout, stream);
+            cur ^= 1;
+        }
+        const uint16_t* g = arena_ + gbuf_off_[cur];       // dL/d(conv output), mask applied
+        if (i == 0) {
+            conv1_wgrad(x, g, grads_ + c.w_off, grads_ + c.b_off, batch, stream);
+        } else {
+            const Conv& prev = convs_[i - 1];
+            const uint16_t* in = arena_ + (prev.pool_after ? prev.pool_off : prev.out_off);
+            ConvShape s = {batch, c.hw, c.cin, c.cout};
+            column_sum(g, grads_ + c.b_off, rows, c.cout, stream);
+            conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream);
+            // input gradient; the producer's ReLU is folded in when nothing sits in between
+            ConvShape d = {batch, c.hw, c.cout, c.cin};
+            const bool fold_relu = !prev.pool_after && !bn_;
+            conv3x3_igemm(g, arena_ + c.wd_off, arena_ + gbuf_off_[cur ^ 1], nullptr,
+                          fold_relu ? arena_ + prev.out_off : nullptr, slab, slab_elems_, d,
+                          fold_relu ? EPI_MASK : EPI_NONE, stream);
+            cur ^= 1;
+        }
+        fire_buckets(i, stream);
+    }
+}
+
+void VggEngine::forward_backward(const uint16_t* x, const int64_t* target, int batch,
+                                 hipStream_t stream) {
+    if (!params_) throw std::logic_error("VggEngine: bind() first");
+    check_hip(hipMemsetAsync(grads_, 0, param_elems_ * sizeof(float), stream), "memset(grads)");
+    check_hip(hipMemsetAsync(ws_ + loss_off_, 0, sizeof(float), stream), "memset(loss)");
+    if (reducer_) reducer_->begin_step();
+    forward(x, batch, true, stream);
+    backward(x, target, batch, stream);
+}
+
+void VggEngine::optimizer_step(float lr, float momentum, float weight_decay, float grad_scale,
+                               hipStream_t stream) {
+    if (reducer_) reducer_->wait_all(stream);
+    sgd_momentum(params_, grads_, mom_, arena_ + shadow_off_, param_elems_, lr, momentum,
+                 weight_decay, grad_scale, false, stream);
+    repack_conv1_weights(params_ + convs_[0].w_off, arena_ + w1_off_, stream);
+    for (size_t i = 1; i < convs_.size(); ++i) {
+        const Conv& c = convs_[i];
+        repack_dgrad_weights(arena_ + shadow_off_ + c.w_off, arena_ + c.wd_off, c.cout, c.cin,
+                             stream);
+    }
+}
+
+void VggEngine::eval_step(const uint16_t* x, const int64_t* target, int batch, hipStream_t stream) {
+    forward(x, batch, false, stream);
+    softmax_xent(ws_ + logits_off_, target, eval_loss(), nullptr, eval_correct(), batch,
+                 num_classes_, 1.0f, stream);
+}
+
+void VggEngine::capture_train_step(const uint16_t* x, const int64_t* target, int batch, float lr,
+                                   float momentum, float weight_decay, float grad_scale,
+                                   hipStream_t stream) {
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
+    const long long saved = bn_steps_;
+    check_hip(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal), "BeginCapture");
+    try {
+        forward_backward(x, target, batch, stream);
+        optimizer_step(lr, momentum, weight_decay, grad_scale, stream);
+    } catch (...) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        bn_steps_ = saved;
+        throw;
+    }
+    check_hip(hipStreamEndCapture(stream, &graph_), "EndCapture");
+    check_hip(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0), "GraphInstantiate");
+    bn_steps_ = saved;      // capturing enqueues nothing
+}
+
+void VggEngine::replay_train_step(hipStream_t stream) {
+    if (!graph_exec_) throw std::logic_error("VggEngine: capture_train_step() first");
+    check_hip(hipGraphLaunch(graph_exec_, stream), "GraphLaunch");
+    if (bn_) ++bn_steps_;
+}
+
+// ------------------------------------------------------------------------- bindings
+void bind_engine(py::module_& m) {
+    py::class_<SlotInfo>(m, "SlotInfo")
+        .def_readonly("name", &SlotInfo::name)
+        .def_readonly("offset", &SlotInfo::offset)
+        .def_readonly("numel", &SlotInfo::numel)
+        .def_readonly("shape", &SlotInfo::shape)
+        .def_readonly("layer", &SlotInfo::layer);
+
+    py::class_<VggEngine>(m, "VggEngine")
+        .def(py::init<const std::vector<int>&, int, bool, int>())
+        .def_property_readonly("param_elems", &VggEngine::param_elems)
+        .def_property_readonly("bn_elems", &VggEngine::bn_elems)
+        .def_property_readonly("arena_elems", &VggEngine::arena_elems)
+        .def_property_readonly("workspace_elems", &VggEngine::workspace_elems)
+        .def_property_readonly("param_slots", &VggEngine::param_slots)
+        .def_property_readonly("buffer_slots", &VggEngine::buffer_slots)
+        .def_property_readonly("num_conv", &VggEngine::num_conv)
+        .def_property("bn_steps", &VggEngine::bn_steps, &VggEngine::set_bn_steps)
+        .def("bind", [](VggEngine& e, uintptr_t p, uintptr_t g, uintptr_t mo, uintptr_t bn,
+                        uintptr_t arena, uintptr_t ws) {
+            e.bind((float*)p, (float*)g, (float*)mo, (float*)bn, (uint16_t*)arena, (float*)ws);
+        })
+        .def("set_reducer", [](VggEngine& e, BucketReducer* r,
+                               std::vector<std::pair<int, int>> buckets) {
+            std::vector<BucketRange> b;
+            for (auto& p : buckets) b.push_back({p.first, p.second});
+            e.set_reducer(r, b);
+        }, py::keep_alive<1, 2>())
+        .def("refresh_weights", [](VggEngine& e, uintptr_t s) { e.refresh_weights((hipStream_t)s); })
+        .def("forward", [](VggEngine& e, uintptr_t x, int batch, bool training, uintptr_t s) {
+            e.forward((const uint16_t*)x, batch, training, (hipStream_t)s);
+        })
+        .def("forward_backward", [](VggEngine& e, uintptr_t x, uintptr_t t, int batch, uintptr_t s) {
+            e.forward_backward((const uint16_t*)x, (const int64_t*)t, batch, (hipStream_t)s);
+        })
+        .def("optimizer_step", [](VggEngine& e, float lr, float mu, float wd, float gs, uintptr_t s) {
+            e.optimizer_step(lr, mu, wd, gs, (hipStream_t)s);
+        })
+        .def("eval_step", [](VggEngine& e, uintptr_t x, uintptr_t t, int batch, uintptr_t s) {
+            e.eval_step((const uint16_t*)x, (const int64_t*)t, batch, (hipStream_t)s);
+        })
+        .def("capture_train_step", [](VggEngine& e, uintptr_t x, uintptr_t t, int batch, float lr,
+                                      float mu, float wd, float gs, uintptr_t s) {
+            e.capture_train_step((const uint16_t*)x, (const int64_t*)t, batch, lr, mu, wd, gs,
+                                 (hipStream_t)s);
+        })
+        .def("replay_train_step", [](VggEngine& e, uintptr_t s) {
+            e.replay_train_step((hipStream_t)s);
+        })
+        .def_property_readonly("has_graph", &VggEngine::has_graph)
+        .def_property_readonly("logits_offset", &VggEngine::logits_offset)
+        .def_property_readonly("loss_offset", &VggEngine::loss_offset)
+        .def_property_readonly("logits_ptr", [](VggEngine& e) { return (uintptr_t)e.logits(); })
+        .def_property_readonly("loss_ptr", [](VggEngine& e) { return (uintptr_t)e.loss(); })
+        .def_property_readonly("eval_loss_ptr", [](VggEngine& e) { return (uintptr_t)e.eval_loss(); })
+        .def_property_readonly("eval_correct_ptr",
+                               [](VggEngine& e) { return (uintptr_t)e.eval_correct(); });
+}
+
+}  // namespace dml

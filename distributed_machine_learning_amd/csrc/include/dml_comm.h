@@ -1,0 +1,132 @@
+// Communication runtime: rendezvous store, RCCL communicator, bucket reducer.
+//
+// Replaces what the reference borrows from torch.distributed: the TCP rendezvous of
+// init_process_group("gloo", "tcp://host:port") (/root/reference/part2/2a/main.py:197),
+// the gather / scatter / all_reduce collectives (part2/2a/main.py:101,114,
+// part2/2b/main.py:106) and DistributedDataParallel's bucketed, backward-overlapped
+// all-reduce with its construction-time broadcast (part3/main.py:137).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace pybind11 { class module_; }
+
+namespace dml {
+
+// ------------------------------------------------------------------------ TcpStore
+// Minimal key-value store over TCP.  The process with is_server=true runs the server in
+// a background thread (and talks to it over loopback like any other client); `get`
+// blocks until the key exists or the timeout expires.
+class TcpStore {
+  public:
+    TcpStore(const std::string& host, int port, bool is_server, int world_size, double timeout_s);
+    ~TcpStore();
+    TcpStore(const TcpStore&) = delete;
+    TcpStore& operator=(const TcpStore&) = delete;
+
+    void set(const std::string& key, const std::string& value);
+    std::string get(const std::string& key);
+    int64_t add(const std::string& key, int64_t delta);
+    // all `world_size` ranks call this with the same name; returns when everyone arrived
+    void barrier(const std::string& name);
+    int port() const { return port_; }
+
+  private:
+    void serve();
+    void request(uint8_t op, const std::string& key, const std::string& val, std::string* out);
+
+    std::string host_;
+    int port_;
+    bool is_server_;
+    int world_size_;
+    double timeout_s_;
+    int listen_fd_ = -1;
+    int client_fd_ = -1;
+    std::thread server_;
+    std::atomic<bool> stop_{false};
+    std::atomic<int> live_clients_{0};
+    std::mutex client_mu_;
+};
+
+// ------------------------------------------------------------------------ RcclComm
+enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_I64 = 2, DT_U8 = 3 };
+
+class RcclComm {
+  public:
+    static std::string unique_id();     // 128 opaque bytes, created on rank 0
+    RcclComm(const std::string& unique_id, int rank, int world_size, int device);
+    ~RcclComm();
+
+    int rank() const { return rank_; }
+    int world_size() const { return world_; }
+
+    void all_reduce(void* buf, size_t count, DType dt, bool average, hipStream_t stream);
+    void broadcast(void* buf, size_t count, DType dt, int root, hipStream_t stream);
+    // root receives rank r's `send` into recv[r]; its own contribution is a device copy
+    void gather(const void* send, const std::vector<void*>& recv, size_t count, DType dt,
+                int root, hipStream_t stream);
+    // rank r receives root's chunks[r] into `out`
+    void scatter(void* out, const std::vector<const void*>& chunks, size_t count, DType dt,
+                 int root, hipStream_t stream);
+    void group_start();
+    void group_end();
+    // Host-side wait for `stream` with a deadline; on expiry or an asynchronous RCCL error
+    // the communicator is aborted and std::runtime_error is thrown, so a dead peer turns
+    // into a clean non-zero exit instead of a hang.
+    void wait_stream(hipStream_t stream, double timeout_s);
+    void destroy();
+    void* raw() const { return comm_; }
+
+  private:
+    void* comm_ = nullptr;      // ncclComm_t
+    int rank_, world_, device_;
+    int group_depth_ = 0;
+};
+
+// ------------------------------------------------------------------- bucket planning
+struct BucketRange { int lo, hi; };     // parameter index range [lo, hi), forward order
+// Walks the tensors back to front; a bucket closes once it has reached its cap (the first
+// bucket uses first_cap_bytes so communication starts early).  Returned in completion order.
+std::vector<BucketRange> plan_buckets(const std::vector<size_t>& sizes_bytes, size_t cap_bytes,
+                                      size_t first_cap_bytes);
+
+// ------------------------------------------------------------------- BucketReducer
+// Overlaps gradient all-reduce with the rest of backward.  Gradients live in one flat
+// fp32 buffer; a bucket is a contiguous element range of it.  `bucket_ready(b, compute)`
+// records an event on the compute stream, makes the communication stream wait on it and
+// enqueues the all-reduce of that slice in place; `wait_all(compute)` makes the compute
+// stream wait for every outstanding bucket (called right before the optimizer kernel).
+// No host synchronisation, no staging copies.
+class BucketReducer {
+  public:
+    struct Slice { size_t offset, count; };
+    BucketReducer(RcclComm* comm, float* flat_grads, std::vector<Slice> slices, bool average,
+                  bool serialize);
+    ~BucketReducer();
+    int num_buckets() const { return (int)slices_.size(); }
+    void begin_step();
+    void bucket_ready(int b, hipStream_t compute);
+    void wait_all(hipStream_t compute);
+    hipStream_t comm_stream() const { return comm_stream_; }
+
+  private:
+    RcclComm* comm_;
+    float* grads_;
+    std::vector<Slice> slices_;
+    bool average_, serialize_;
+    hipStream_t comm_stream_ = nullptr;
+    std::vector<hipEvent_t> ready_, done_;
+    std::vector<char> launched_;
+};
+
+void bind_comm(pybind11::module_& m);
+
+}  // namespace dml

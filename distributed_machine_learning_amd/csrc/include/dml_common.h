@@ -1,0 +1,69 @@
+// Shared device-side helpers for the gfx950 (CDNA4) kernels.
+//
+// Conventions used by every kernel in this directory:
+//   * wavefront = 64 lanes, workgroups are multiples of 64 threads;
+//   * activations are NHWC bf16, master parameters / gradients / statistics are fp32;
+//   * bf16 travels through memory as 16-byte (8-element) vectors wherever possible.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dml {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float bf16_bits_to_float(uint16_t b) {
+    return __builtin_bit_cast(float, (uint32_t)b << 16);
+}
+
+__device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved)
+    return __builtin_bit_cast(uint16_t, (bf16_t)f);
+}
+
+// 8 bf16 packed in a uint4 -> 8 floats
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+}
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)float_to_bf16_bits(lo) | ((uint32_t)float_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 v;
+    v.x = pack2(f[0], f[1]);
+    v.y = pack2(f[2], f[3]);
+    v.z = pack2(f[4], f[5]);
+    v.w = pack2(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+}  // namespace dml

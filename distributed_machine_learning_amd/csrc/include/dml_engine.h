@@ -1,0 +1,122 @@
+// Static-plan training engine for the VGG family.
+//
+// The reference drives every iteration from Python through torch.nn modules and the
+// autograd engine (/root/reference/part1/main.py:38-46: zero_grad, forward, loss,
+// backward, step).  At MI355X speeds an iteration is about a millisecond, so the per-op
+// Python/autograd cost would dominate.  This engine instead walks a fixed layer plan in
+// C++ and enqueues every kernel of forward, loss, backward (with the bucket reducer's
+// hooks between layers) and the optimizer on one HIP stream; nothing in a step touches
+// the host allocator or synchronises, so a whole step can also be captured in a hipGraph.
+//
+// Memory is provided by the caller as six flat device buffers (so torch owns the
+// allocations and can view them as tensors):
+//   params / grads / momentum : fp32, parameter slots in named_parameters() order; conv
+//                               weights stored [cout][3][3][cin] (KRSC), fc [10][512]
+//   bn_buffers                : fp32 running_mean / running_var slots
+//   arena                     : bf16 - weight shadows, dgrad-layout weights, activations,
+//                               gradient ping-pong buffers
+//   workspace                 : fp32 - logits, dlogits, loss / accuracy accumulators,
+//                               BatchNorm saved statistics, split-K slabs
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "dml_comm.h"
+
+namespace pybind11 { class module_; }
+
+namespace dml {
+
+struct SlotInfo {
+    std::string name;          // state_dict key, e.g. "layers.3.weight"
+    size_t offset;             // elements into the flat buffer
+    size_t numel;
+    std::vector<int> shape;    // internal layout ([cout,3,3,cin] for conv weights)
+    int layer;                 // conv layer index, or n_conv for the classifier
+};
+
+class VggEngine {
+  public:
+    // widths: output channels per conv layer, -1 for a 2x2 max-pool (the VGG width table)
+    VggEngine(const std::vector<int>& widths, int max_batch, bool batch_norm, int num_classes);
+
+    size_t param_elems() const { return param_elems_; }
+    size_t bn_elems() const { return bn_elems_; }
+    size_t arena_elems() const { return arena_elems_; }
+    size_t workspace_elems() const { return ws_elems_; }
+    const std::vector<SlotInfo>& param_slots() const { return slots_; }
+    const std::vector<SlotInfo>& buffer_slots() const { return bn_slots_; }
+
+    void bind(float* params, float* grads, float* momentum, float* bn_buffers, uint16_t* arena,
+              float* workspace);
+    void set_reducer(BucketReducer* reducer, const std::vector<BucketRange>& buckets);
+
+    // bf16 shadow + conv1 / dgrad repacks from the fp32 master weights
+    void refresh_weights(hipStream_t stream);
+    // zero grads, forward (training), loss, backward; reducer hooks fire between layers
+    void forward_backward(const uint16_t* x_nhwc4, const int64_t* target, int batch,
+                          hipStream_t stream);
+    // waits for the reducer (if any), fused SGD over the flat buffers, refresh_weights
+    void optimizer_step(float lr, float momentum, float weight_decay, float grad_scale,
+                        hipStream_t stream);
+    // forward only (evaluation statistics); accumulates loss / correct into the eval slots
+    void eval_step(const uint16_t* x_nhwc4, const int64_t* target, int batch, hipStream_t stream);
+    void forward(const uint16_t* x_nhwc4, int batch, bool training, hipStream_t stream);
+
+    // hipGraph capture of forward_backward + optimizer_step on fixed input buffers
+    void capture_train_step(const uint16_t* x_nhwc4, const int64_t* target, int batch, float lr,
+                            float momentum, float weight_decay, float grad_scale,
+                            hipStream_t stream);
+    void replay_train_step(hipStream_t stream);
+    bool has_graph() const { return graph_exec_ != nullptr; }
+
+    // workspace addresses the Python side reads
+    float* logits() const { return ws_ + logits_off_; }
+    float* loss() const { return ws_ + loss_off_; }             // mean loss of the last step
+    float* eval_loss() const { return ws_ + loss_off_ + 1; }    // sum of per-batch means
+    int32_t* eval_correct() const { return (int32_t*)(ws_ + loss_off_ + 2); }
+    size_t logits_offset() const { return logits_off_; }
+    size_t loss_offset() const { return loss_off_; }   // [loss, eval_loss, eval_correct(int32)]
+    long long bn_steps() const { return bn_steps_; }
+    void set_bn_steps(long long v) { bn_steps_ = v; }
+    int num_conv() const { return (int)convs_.size(); }
+    ~VggEngine();
+
+  private:
+    struct Conv {
+        int cin, cout, hw;
+        bool pool_after;
+        size_t w_off, b_off, gamma_off, beta_off;     // flat params
+        size_t rm_off, rv_off;                        // bn_buffers
+        size_t save_off;                              // workspace: mean[c], rstd[c]
+        size_t wd_off;                                // arena: dgrad-layout weights
+        size_t pre_off, out_off, pool_off;            // arena: activations
+    };
+    void backward(const uint16_t* x_nhwc4, const int64_t* target, int batch, hipStream_t stream);
+    void fire_buckets(int layer, hipStream_t stream);
+
+    std::vector<Conv> convs_;
+    int max_batch_, num_classes_, fc_in_;
+    bool bn_;
+    size_t fcw_off_ = 0, fcb_off_ = 0;
+    size_t param_elems_ = 0, bn_elems_ = 0, arena_elems_ = 0, ws_elems_ = 0;
+    size_t shadow_off_ = 0, w1_off_ = 0, gbuf_off_[2] = {0, 0};
+    size_t logits_off_ = 0, dlogits_off_ = 0, loss_off_ = 0, stats_off_ = 0, slab_off_ = 0;
+    size_t slab_elems_ = 0;
+    std::vector<SlotInfo> slots_, bn_slots_;
+    float *params_ = nullptr, *grads_ = nullptr, *mom_ = nullptr, *bnbuf_ = nullptr, *ws_ = nullptr;
+    uint16_t* arena_ = nullptr;
+    BucketReducer* reducer_ = nullptr;
+    std::vector<std::vector<int>> buckets_by_layer_;   // layer -> bucket ids to fire
+    long long bn_steps_ = 0;
+    hipGraph_t graph_ = nullptr;
+    hipGraphExec_t graph_exec_ = nullptr;
+};
+
+void bind_engine(pybind11::module_& m);
+
+}  // namespace dml

@@ -1,0 +1,130 @@
+// Host-side launch API of the gfx950 kernels.  Every function validates its shapes on
+// the host (throws std::invalid_argument), enqueues on `stream` and returns; nothing
+// here allocates or synchronises, so all of it can be captured into a hipGraph.
+//
+// Kernel inventory (call sites in the reference, /root/reference/part1/model.py and
+// /root/reference/part1/main.py):
+//   conv3x3 fwd / bwd-data / bwd-weight  <- nn.Conv2d(k=3, s=1, p=1)   model.py:18-23
+//   BatchNorm+ReLU fwd / bwd             <- nn.BatchNorm2d + nn.ReLU    part3/model.py:24-25
+//   maxpool 2x2 fwd / bwd                <- nn.MaxPool2d(2, 2)          model.py:16
+//   linear fwd / bwd                     <- nn.Linear(512, 10)          model.py:40,45
+//   softmax cross-entropy fwd+bwd, top-1 <- nn.CrossEntropyLoss, argmax main.py:43,70-72
+//   SGD momentum / weight decay          <- optim.SGD(...).step()       main.py:120-121,46
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dml {
+
+typedef uint16_t bf16_raw;   // bf16 bit pattern in host-visible signatures
+
+// ---------------------------------------------------------------- conv3x3 (stride 1, pad 1)
+enum ConvEpilogue : int {
+    EPI_NONE = 0,       // y = acc
+    EPI_BIAS = 1,       // y = acc + bias[n]
+    EPI_BIAS_RELU = 2,  // y = max(acc + bias[n], 0)
+    EPI_MASK = 3,       // y = mask[m][n] > 0 ? acc : 0     (ReLU backward folded into dgrad)
+};
+
+struct ConvShape {
+    int batch;   // images
+    int hw;      // square spatial size, power of two (32 .. 1)
+    int cin;     // input channels of the GEMM's reduction (multiple of 64)
+    int cout;    // output channels of the GEMM (multiple of 64)
+};
+
+// Implicit GEMM  y[m][n] = sum_{tap,c} x[m (+) tap][c] * w[n][tap][c],  m = (b,h,w) NHWC.
+// Forward: x = activations, w = weights [cout][9][cin].  Backward-data: x = dy,
+// w = repacked weights [cin][9 flipped][cout] (see repack_dgrad_weights), roles of
+// cin/cout swapped by the caller.  `workspace` (fp32, >= splits*M*N elements) is used
+// when the launcher decides to split the reduction over taps.
+void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
+                   const bf16_raw* mask, float* workspace, size_t workspace_elems,
+                   ConvShape s, ConvEpilogue epi, hipStream_t stream);
+size_t conv3x3_igemm_workspace_elems(ConvShape s);
+
+// First layer: x is [B,32,32,4] bf16 (3 channels + zero pad), w1 is [64][64] bf16 with
+// k = tap*4 + c (k >= 36 zero), y = relu?(conv + bias) as [B,32,32,64] bf16.
+void conv1_fprop(const bf16_raw* x, const bf16_raw* w1, const float* bias, bf16_raw* y,
+                 int batch, bool relu, hipStream_t stream);
+// dW1[64][9][3] += sum_p dy[p][co] * x[p (+) tap][c],  db[64] += sum_p dy[p][co]  (fp32 atomics,
+// outputs must be zeroed by the caller).
+void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, int batch,
+                 hipStream_t stream);
+
+// dw[cout][9][cin] (+)= sum_p dy[p][cout] * x[p (+) tap][cin]   (fp32).  With more than one
+// split the kernel accumulates with atomics and `dw` must be zeroed by the caller.
+void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
+                   hipStream_t stream);
+
+// wd[cin][8 - tap][cout] = wf[cout][tap][cin]   (bf16 -> bf16)
+void repack_dgrad_weights(const bf16_raw* wf, bf16_raw* wd, int cout, int cin, hipStream_t stream);
+// w1[64][64] bf16 (k = tap*4 + c) from master fp32 [64][9][3]
+void repack_conv1_weights(const float* w, bf16_raw* w1, hipStream_t stream);
+
+// out[c] += sum_m x[m][c]   (fp32 atomics; out zeroed by the caller)
+void column_sum(const bf16_raw* x, float* out, int rows, int cols, hipStream_t stream);
+
+// ---------------------------------------------------------------- maxpool 2x2 stride 2
+void maxpool2x2_fwd(const bf16_raw* x, bf16_raw* y, int batch, int hw, int c, hipStream_t stream);
+// dx = dy routed to the first maximum of each window; with relu_mask the route is also
+// closed where x <= 0 (x is a post-ReLU tensor).
+void maxpool2x2_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, int batch, int hw, int c,
+                    bool relu_mask, hipStream_t stream);
+
+// ---------------------------------------------------------------- BatchNorm + ReLU (NHWC)
+// Training forward: batch statistics over rows, y = relu(gamma * (x - mean) * rstd + beta),
+// running stats updated with `momentum` (unbiased variance), save_mean/save_rstd kept for
+// backward.  `stats_ws` is 2*c floats of scratch.
+void bn_relu_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* save_mean,
+                       float* save_rstd, float* stats_ws, int rows, int c, float momentum,
+                       float eps, hipStream_t stream);
+void bn_relu_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, int rows, int c,
+                      float eps, hipStream_t stream);
+// dx, dgamma, dbeta from dy (grad of the ReLU output), the saved input x and statistics.
+// `stats_ws` is 2*c floats of scratch; dgamma/dbeta are overwritten.
+void bn_relu_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+                 const float* beta, const float* save_mean, const float* save_rstd,
+                 float* dgamma, float* dbeta, float* stats_ws, int rows, int c,
+                 hipStream_t stream);
+
+// ---------------------------------------------------------------- classifier + loss
+// logits[b][n] = sum_k x[b][k] * w[n][k] + bias[n]      (x bf16, w/bias/logits fp32, n <= 16)
+void linear_fwd(const bf16_raw* x, const float* w, const float* bias, float* logits, int batch,
+                int in_features, int out_features, hipStream_t stream);
+// dw (+)= dlogits^T x, db (+)= sum dlogits, dx = dlogits w  (dx bf16).  accumulate=false overwrites.
+void linear_bwd(const bf16_raw* x, const float* w, const float* dlogits, float* dw, float* db,
+                bf16_raw* dx, int batch, int in_features, int out_features, hipStream_t stream);
+// Mean cross-entropy over the batch: loss_sum[0] += sum_b loss_b / batch,
+// dlogits = (softmax - onehot) * grad_scale / batch (may be null), correct[0] += #(argmax == target).
+void softmax_xent(const float* logits, const int64_t* target, float* loss_sum, float* dlogits,
+                  int32_t* correct, int batch, int classes, float grad_scale, hipStream_t stream);
+
+// ---------------------------------------------------------------- optimiser
+// g' = g * grad_scale + wd * p;  m = first ? g' : mu * m + g';  p -= lr * m.
+// Also writes the bf16 shadow copy of p when `shadow` is non-null.
+void sgd_momentum(float* p, const float* g, float* m, bf16_raw* shadow, size_t n, float lr,
+                  float mu, float wd, float grad_scale, bool first_step, hipStream_t stream);
+
+// out[i] = bf16(x[i])
+void cast_f32_to_bf16(const float* x, bf16_raw* out, size_t n, hipStream_t stream);
+
+// ---------------------------------------------------------------- data / layout / comm helpers
+// uint8 [B,32,32,3] -> bf16 [B,32,32,4], random-crop(pad 4)+flip per aug row (may be null),
+// /255, normalise.  aug = int32 [B,3] (row offset, col offset, flip).
+void augment_normalize(const uint8_t* images, const int32_t* aug, bf16_raw* out, int batch,
+                       const float mean[3], const float stdv[3], hipStream_t stream);
+// fp32 NCHW [B,3,32,32] -> bf16 NHWC4
+void nchw_to_nhwc4(const float* x, bf16_raw* out, int batch, hipStream_t stream);
+// fp32 NCHW <-> bf16 NHWC for generic tensors
+void nchw_f32_to_nhwc_bf16(const float* x, bf16_raw* out, int batch, int c, int hw, hipStream_t s);
+void nhwc_bf16_to_nchw_f32(const bf16_raw* x, float* out, int batch, int c, int hw, hipStream_t s);
+// slabs[0][i] += slabs[1][i] + ... + slabs[w-1][i]   (root-side reduction of gather/scatter)
+void sum_slabs(float* slabs, int world, size_t n, hipStream_t stream);
+// fill a bf16 buffer with uniform values in [-1, 1) from a counter hash (tests / benches)
+void fill_uniform_bf16(bf16_raw* out, size_t n, uint32_t seed, float scale, hipStream_t stream);
+
+}  // namespace dml

@@ -1,0 +1,224 @@
+// First layer: conv3x3 with 3 input channels (forward and backward-weight).
+//
+// Reference op: the first nn.Conv2d(3, 64, 3, padding=1) of the Sequential
+// (/root/reference/part1/model.py:13,18-23).  Its input needs no gradient, so there is
+// no backward-data kernel.
+//
+// With C = 3 the reduction is only 27 long and the layer is bound by the 64-channel
+// 32x32 output (the largest activation of the network), not by math.  The input is kept
+// as NHWC with the channel padded to 4 (one 8-byte load per tap); the im2col row of a
+// pixel is k = tap*4 + c for 9 taps (36 values) padded with zeros to K = 64, built by the
+// thread that owns the pixel and written to LDS once.  The product itself runs on the
+// matrix cores (v_mfma_f32_16x16x32_bf16 forward, 32x32x16 with transposing LDS reads
+// backward) so the VALU is left for the gather and the epilogue.
+//
+// Backward-weight trick: im2col column k = 36 is set to 1.0, so the same MFMA that
+// produces dW[co][k] yields the bias gradient sum_p dy[p][co] in column 36 for free.
+#include <stdexcept>
+
+#include "dml_common.h"
+#include "dml_kernels.h"
+
+namespace dml {
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_c1;
+
+// im2col taps (t0, t0+1) of pixel `pix` as one 16-byte chunk; tap index >= 9 gives zeros.
+__device__ __forceinline__ uint2 load_tap(const uint16_t* x, int pix, int h, int w, int tap,
+                                          bool row_ok) {
+    const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+    const bool ok = row_ok && tap < 9 && (unsigned)(h + dh) < 32u && (unsigned)(w + dw) < 32u;
+    return ok ? *(const uint2*)(x + (size_t)(pix + dh * 32 + dw) * 4) : make_uint2(0, 0);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------- forward
+// Block: 256 pixels x 64 output channels, K = 64 in one step.  Wave w owns pixels
+// [64w, 64w+64).  Accumulator layout D[co][pixel] as in the generic kernel.
+__global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __restrict__ x,
+                                                          const uint16_t* __restrict__ w1,
+                                                          const float* __restrict__ bias,
+                                                          uint16_t* __restrict__ y, int M,
+                                                          int relu) {
+    __shared__ __attribute__((aligned(16))) char smem[(256 + 64) * 128];
+    char* sA = smem;                 // [256 px][64 k]
+    char* sB = smem + 256 * 128;     // [64 co][64 k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pix = blockIdx.x * 256 + tid;
+    const bool row_ok = pix < M;
+    const int w_ = pix & 31, h_ = (pix >> 5) & 31;
+    const int sw_row = (tid >> 1) & 7;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < 5) {
+            const uint2 a = load_tap(x, pix, h_, w_, 2 * c, row_ok);
+            const uint2 b = load_tap(x, pix, h_, w_, 2 * c + 1, row_ok);
+            v = make_uint4(a.x, a.y, b.x, b.y);
+        }
+        *(uint4*)(sA + tid * 128 + ((c ^ sw_row) << 4)) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int chunk = tid + 256 * i;
+        const int r = chunk >> 3, c = chunk & 7;
+        *(uint4*)(sB + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = *(const uint4*)(w1 + r * 64 + c * 8);
+    }
+    __syncthreads();
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, lq = lane >> 4, sw = l15 >> 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int koff = ((kk * 4 + lq) ^ sw) << 4;
+        bf16x8 wf[4], xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(sB + (i * 16 + l15) * 128 + koff);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            xf[j] = *(const bf16x8*)(sA + (wave * 64 + j * 16 + l15) * 128 + koff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = blockIdx.x * 256 + wave * 64 + j * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = i * 16 + lq * 4;
+            const float4 b = *(const float4*)(bias + n);
+            float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z,
+                  v3 = acc[i][j][3] + b.w;
+            if (relu) {
+                v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+            }
+            uint2 o;
+            o.x = pack2(v0, v1);
+            o.y = pack2(v2, v3);
+            *(uint2*)(y + (size_t)m * 64 + n) = o;
+        }
+    }
+}
+
+void conv1_fprop(const bf16_raw* x, const bf16_raw* w1, const float* bias, bf16_raw* y, int batch,
+                 bool relu, hipStream_t stream) {
+    if (batch <= 0) return;
+    if ((long long)batch * 1024 * 64 >= (1LL << 31))
+        throw std::invalid_argument("conv1_fprop: batch too large");
+    const int M = batch * 1024;
+    hipLaunchKernelGGL(conv1_fprop_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, x, w1, bias,
+                       y, M, relu ? 1 : 0);
+}
+
+// ------------------------------------------------------------------ backward-weight
+// D[co][k] = sum_p dy[p][co] * col[p][k] over this block's pixel range; 4 waves = the four
+// 32x32 tiles of the 64x64 result.  Row stride 192 B keeps the transposing reads
+// conflict-free.  Result is added to dw[64][9][3] / db[64] with fp32 atomics.
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __restrict__ x,
+                                                          const uint16_t* __restrict__ dy,
+                                                          float* __restrict__ dw,
+                                                          float* __restrict__ db, int M,
+                                                          int steps_per_block) {
+    constexpr int S = 192;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * S];
+    char* sD = smem;               // dy tile  [64 px][64 co]
+    char* sC = smem + 64 * S;      // im2col   [64 px][64 k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tco = wave & 1, tk = wave >> 1;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int frag_row = 8 * (g >> 1) + q, frag_col = 16 * (g & 1) + 4 * pp;
+    const int a_off = frag_row * S + (tco * 32 + frag_col) * 2;
+    const int b_off = frag_row * S + (tk * 32 + frag_col) * 2;
+
+    const int total_steps = (M + 63) / 64;
+    const int s0 = blockIdx.x * steps_per_block;
+    const int s1 = min(total_steps, s0 + steps_per_block);
+    const int crow = tid >> 2, cq = tid & 3;      // im2col staging: row, quarter
+    for (int s = s0; s < s1; ++s) {
+        const int pbase = s * 64;
+        // dy tile: 512 chunks, two per thread
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int chunk = tid + 256 * i;
+            const int r = chunk >> 3, c = chunk & 7;
+            const int pix = pbase + r;
+            const uint4 v = pix < M ? *(const uint4*)(dy + (size_t)pix * 64 + c * 8)
+                                    : make_uint4(0, 0, 0, 0);
+            *(uint4*)(sD + r * S + c * 16) = v;
+        }
+        // im2col tile: thread (row, quarter) writes chunks 2*cq and 2*cq + 1
+        {
+            const int pix = pbase + crow;
+            const bool ok = pix < M;
+            const int w_ = pix & 31, h_ = (pix >> 5) & 31;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int c = 2 * cq + cc;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (c < 5) {
+                    const uint2 a = load_tap(x, pix, h_, w_, 2 * c, ok);
+                    uint2 b = load_tap(x, pix, h_, w_, 2 * c + 1, ok);
+                    if (c == 4 && ok) b.x = 0x3f80u;      // k = 36 -> bf16 1.0 (bias column)
+                    v = make_uint4(a.x, a.y, b.x, b.y);
+                }
+                *(uint4*)(sC + crow * S + c * 16) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const char* pa = sD + a_off + ks * 16 * S;
+            const char* pb = sC + b_off + ks * 16 * S;
+            const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_c1*)pa);
+            const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_c1*)(pa + 4 * S));
+            const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_c1*)pb);
+            const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_c1*)(pb + 4 * S));
+            const s16x8 av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+            const s16x8 bv = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                          __builtin_bit_cast(bf16x8, bv), acc, 0, 0,
+                                                          0);
+        }
+        __syncthreads();
+    }
+    if (s0 >= s1) return;
+    // D[co][k]: lane -> k = tk*32 + (l & 31); register r -> co
+    const int k = tk * 32 + (lane & 31), lh = lane >> 5;
+    const int tap = k >> 2, c = k & 3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = tco * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (tap < 9 && c < 3) atomicAdd(dw + co * 27 + tap * 3 + c, acc[r]);
+        else if (k == 36 && db) atomicAdd(db + co, acc[r]);
+    }
+}
+
+void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, int batch,
+                 hipStream_t stream) {
+    if (batch <= 0) return;
+    const int M = batch * 1024;
+    const int total_steps = (M + 63) / 64;
+    int blocks = total_steps < 512 ? total_steps : 512;
+    const int spb = (total_steps + blocks - 1) / blocks;
+    blocks = (total_steps + spb - 1) / spb;
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, dw, db, M,
+                       spb);
+}
+
+}  // namespace dml

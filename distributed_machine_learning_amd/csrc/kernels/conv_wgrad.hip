@@ -1,0 +1,297 @@
+// conv3x3 backward-weight as an MFMA implicit GEMM, plus the weight repack for dgrad.
+//
+// Reference op: the weight / bias gradient autograd computes for nn.Conv2d
+// (/root/reference/part1/model.py:18-23) inside loss.backward()
+// (/root/reference/part1/main.py:44).
+//
+//   dw[co][tap][ci] = sum_p dy[p][co] * x[p (+) tap][ci]            p = (b, h, w)
+//
+// GEMM view per tap: D[co][ci] = dyT[co][p] * xs[p][ci]; the reduction runs over pixels,
+// and both operands are stored pixel-major ([p][channel], NHWC), i.e. K-strided for the
+// matrix cores.  Tiles are staged in LDS exactly as they sit in memory ([64 px][channels])
+// and the MFMA fragments are fetched with ds_read_b64_tr_b16, gfx950's transposing LDS
+// read: per 16 lanes it takes a 4 (pixels) x 16 (channels) block and hands each lane the
+// four pixels of one channel, so two reads give the 8 consecutive-K values a lane needs.
+//
+// CDNA4 mapping
+//   * block = 256 threads (4 wave64, 2x2), tile BCO x BCI channels of ONE tap, K step
+//     64 pixels = 4 x v_mfma_f32_32x32x16_bf16 per 32x32 tile.
+//   * 32x32 accumulators put 32 consecutive ci on lanes 0..31 of one register, so the
+//     fp32 result leaves as 128-byte row segments - the shape at which global fp32
+//     atomics run at full rate when the pixel range is split across blocks.
+//   * LDS rows are padded by 64 bytes (row stride = 2*channels + 64): the four pixel rows
+//     and two 16-channel groups touched by one half-wave of a transposing read then hit
+//     disjoint banks.
+//   * Two LDS stages, register staging, one barrier per K step (same pipeline as fprop).
+//   * The pixel range is split over blockIdx.y until the grid covers the chip; partial
+//     sums are combined with fp32 atomics into the (pre-zeroed) flat gradient buffer.
+#include <stdexcept>
+#include <string>
+
+#include "dml_common.h"
+#include "dml_kernels.h"
+
+namespace dml {
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* row_ptr, int row_stride) {
+    // rows k..k+3 then k+4..k+7 of the block this lane addresses
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row_ptr));
+    const s16x4 hi =
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row_ptr + 4 * row_stride));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+struct WgradArgs {
+    const uint16_t* x;
+    const uint16_t* dy;
+    float* dw;
+    int M, Cin, Cout;
+    int hw, log_hw;
+    int tiles_ci, tiles_co;
+    int steps_per_split;   // K steps (64 pixels each) per blockIdx.y
+    int atomic;
+};
+
+template <int BCO, int BCI>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
+    constexpr int SA = BCO * 2 + 64;          // dy tile row stride (bytes)
+    constexpr int SB = BCI * 2 + 64;          // x  tile row stride
+    constexpr int STAGE = 64 * (SA + SB);
+    constexpr int WCO = BCO / 2, WCI = BCI / 2;      // wave tile
+    constexpr int TCO = WCO / 32, TCI = WCI / 32;
+    constexpr int A_CH = BCO / 8, B_CH = BCI / 8;    // 16-byte chunks per row
+    constexpr int A_IT = 64 * A_CH / 256, B_IT = 64 * B_CH / 256;
+    static_assert(TCO >= 1 && TCI >= 1, "wave tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave & 1, wci = wave >> 1;
+
+    int t = blockIdx.x;
+    const int tile_ci = t % p.tiles_ci; t /= p.tiles_ci;
+    const int tile_co = t % p.tiles_co; t /= p.tiles_co;
+    const int tap = t;
+    const int co0 = tile_co * BCO, ci0 = tile_ci * BCI;
+    const int dh = tap / 3 - 1, dw_ = tap % 3 - 1;
+    const int hw = p.hw;
+
+    const int total_steps = (p.M + 63) / 64;
+    const int s_begin = blockIdx.y * p.steps_per_split;
+    const int s_end = min(total_steps, s_begin + p.steps_per_split);
+
+    const int a_c = tid % A_CH, a_r = tid / A_CH;       // dy staging ownership
+    const int b_c = tid % B_CH, b_r = tid / B_CH;       // x staging ownership
+    constexpr int A_RSTEP = 256 / A_CH, B_RSTEP = 256 / B_CH;
+
+    uint4 ra[A_IT], rb[B_IT];
+    auto load_step = [&](int s) {
+        const int pbase = s * 64;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int pix = pbase + a_r + i * A_RSTEP;
+            ra[i] = (pix < p.M)
+                        ? *(const uint4*)(p.dy + (size_t)pix * p.Cout + co0 + a_c * 8)
+                        : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int pix = pbase + b_r + i * B_RSTEP;
+            const int ww = (pix & (hw - 1)) + dw_;
+            const int hh = ((pix >> p.log_hw) & (hw - 1)) + dh;
+            const bool ok = pix < p.M && (unsigned)hh < (unsigned)hw && (unsigned)ww < (unsigned)hw;
+            rb[i] = ok ? *(const uint4*)(p.x + (size_t)(pix + dh * hw + dw_) * p.Cin + ci0 + b_c * 8)
+                       : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_step = [&](int stage) {
+        char* sA = smem + stage * STAGE;
+        char* sB = sA + 64 * SA;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            *(uint4*)(sA + (a_r + i * A_RSTEP) * SA + a_c * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            *(uint4*)(sB + (b_r + i * B_RSTEP) * SB + b_c * 16) = rb[i];
+    };
+
+    f32x16 acc[TCO][TCI];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TCI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing-read addressing: 16-lane group g = lane>>4 covers channels 16*(g&1).. of
+    // the 32-wide tile and K rows 8*(g>>1)..; inside the group lane 4q+pp addresses row q,
+    // channels 4pp..4pp+3.
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int frag_row = 8 * (g >> 1) + q;
+    const int frag_col = 16 * (g & 1) + 4 * pp;
+    const int a_off = frag_row * SA + (wco * WCO + frag_col) * 2;
+    const int b_off = 64 * SA + frag_row * SB + (wci * WCI + frag_col) * 2;
+
+    auto compute = [&](int stage) {
+        const char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[TCO], bfr[TCI];
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+                af[i] = tr_frag(base + a_off + ks * 16 * SA + i * 64, SA);
+#pragma unroll
+            for (int j = 0; j < TCI; ++j)
+                bfr[j] = tr_frag(base + b_off + ks * 16 * SB + j * 64, SB);
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                for (int j = 0; j < TCI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j],
+                                                                        0, 0, 0);
+        }
+    };
+
+    if (s_begin < s_end) {
+        load_step(s_begin);
+        store_step(0);
+        __syncthreads();
+        for (int s = s_begin; s < s_end; ++s) {
+            const bool more = s + 1 < s_end;
+            const int st = (s - s_begin) & 1;
+            if (more) load_step(s + 1);
+            compute(st);
+            if (more) store_step(st ^ 1);
+            __syncthreads();
+        }
+    } else {
+        return;
+    }
+
+    // D[co][ci]: lane -> ci = l & 31, register r -> co = (r&3) + 8*(r>>2) + 4*(l>>5)
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TCO; ++i) {
+#pragma unroll
+        for (int j = 0; j < TCI; ++j) {
+            const int ci = ci0 + wci * WCI + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float* dst = p.dw + ((size_t)co * 9 + tap) * p.Cin + ci;
+                if (p.atomic) atomicAdd(dst, acc[i][j][r]);
+                else *dst = acc[i][j][r];
+            }
+        }
+    }
+}
+
+int ilog2w(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+template <int BCO, int BCI>
+void launch_wgrad(WgradArgs a, hipStream_t stream) {
+    a.tiles_co = a.Cout / BCO;
+    a.tiles_ci = a.Cin / BCI;
+    const int tiles = a.tiles_co * a.tiles_ci * 9;
+    const int total_steps = (a.M + 63) / 64;
+    // split the pixel range until ~1.1 blocks per CU, keeping >= 4 K steps per block
+    int splits = (288 + tiles - 1) / tiles;
+    const int max_splits = total_steps >= 4 ? total_steps / 4 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    a.steps_per_split = (total_steps + splits - 1) / splits;
+    splits = (total_steps + a.steps_per_split - 1) / a.steps_per_split;
+    a.atomic = splits > 1 ? 1 : 0;
+    constexpr int lds = 2 * 64 * ((BCO * 2 + 64) + (BCI * 2 + 64));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<BCO, BCI>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<BCO, BCI>), dim3(tiles, splits), dim3(256), lds,
+                       stream, a);
+}
+
+}  // namespace
+
+void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
+                   hipStream_t stream) {
+    if (s.batch <= 0 || s.hw < 1 || s.hw > 32 || (s.hw & (s.hw - 1)) || s.cin % 64 ||
+        s.cout % 128 || s.cin < 64)
+        throw std::invalid_argument("conv3x3_wgrad: needs hw power of two <= 32, cin % 64 == 0, "
+                                    "cout % 128 == 0");
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.dw = dw;
+    a.M = s.batch * s.hw * s.hw; a.Cin = s.cin; a.Cout = s.cout;
+    a.hw = s.hw; a.log_hw = ilog2w(s.hw);
+    a.tiles_ci = a.tiles_co = 0; a.steps_per_split = 0; a.atomic = 0;
+    if (s.cin % 128 == 0) launch_wgrad<128, 128>(a, stream);
+    else launch_wgrad<128, 64>(a, stream);
+}
+
+// ------------------------------------------------------------------ weight repacks
+// wd[ci][8 - tap][co] = wf[co][tap][ci]: a 64x64 bf16 transpose per (tap, tile) through LDS.
+__global__ __launch_bounds__(256) void repack_dgrad_kernel(const uint16_t* __restrict__ wf,
+                                                           uint16_t* __restrict__ wd, int cout,
+                                                           int cin) {
+    __shared__ uint16_t tile[64][66];
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, tap = blockIdx.z;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int chunk = tid + 256 * i;          // 512 chunks of 8 elements
+        const int r = chunk >> 3, c = (chunk & 7) * 8;
+        const uint4 v = *(const uint4*)(wf + ((size_t)(co0 + r) * 9 + tap) * cin + ci0 + c);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tile[r][c + 2 * e] = (uint16_t)(w[e] & 0xffff);
+            tile[r][c + 2 * e + 1] = (uint16_t)(w[e] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int chunk = tid + 256 * i;
+        const int r = chunk >> 3, c = (chunk & 7) * 8;   // r = ci row, c = co offset
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            w[e] = (uint32_t)tile[c + 2 * e][r] | ((uint32_t)tile[c + 2 * e + 1][r] << 16);
+        *(uint4*)(wd + ((size_t)(ci0 + r) * 9 + (8 - tap)) * cout + co0 + c) =
+            make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+void repack_dgrad_weights(const bf16_raw* wf, bf16_raw* wd, int cout, int cin, hipStream_t stream) {
+    if (cout % 64 || cin % 64) throw std::invalid_argument("repack_dgrad_weights: dims % 64 != 0");
+    hipLaunchKernelGGL(repack_dgrad_kernel, dim3(cin / 64, cout / 64, 9), dim3(256), 0, stream, wf,
+                       wd, cout, cin);
+}
+
+__global__ __launch_bounds__(256) void repack_conv1_kernel(const float* __restrict__ w,
+                                                           uint16_t* __restrict__ w1) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // 64 * 64
+    if (idx >= 4096) return;
+    const int co = idx >> 6, k = idx & 63;
+    const int tap = k >> 2, c = k & 3;
+    float v = 0.f;
+    if (tap < 9 && c < 3) v = w[co * 27 + tap * 3 + c];
+    w1[idx] = float_to_bf16_bits(v);
+}
+
+void repack_conv1_weights(const float* w, bf16_raw* w1, hipStream_t stream) {
+    hipLaunchKernelGGL(repack_conv1_kernel, dim3(16), dim3(256), 0, stream, w, w1);
+}
+
+}  // namespace dml

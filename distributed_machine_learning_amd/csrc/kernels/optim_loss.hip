@@ -1,0 +1,236 @@
+// Fused SGD (momentum + weight decay), the linear classifier and softmax cross-entropy.
+//
+// Reference call sites: optim.SGD(lr=0.1, momentum=0.9, weight_decay=1e-4).step()
+// (/root/reference/part1/main.py:120-121,46), nn.Linear(512, 10)
+// (/root/reference/part1/model.py:40,45), nn.CrossEntropyLoss and the top-1 count in
+// test_model (/root/reference/part1/main.py:115,43,70-72).
+#include <stdexcept>
+
+#include "dml_common.h"
+#include "dml_kernels.h"
+
+namespace dml {
+
+// ------------------------------------------------------------------------------- SGD
+// One launch updates the whole model: p, g, m are the flat fp32 buffers.  Memory-bound:
+// 16 B/lane loads and stores, grid capped at 2048 blocks with a grid-stride loop.
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(
+    float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+    uint2* __restrict__ shadow, size_t n4, float lr, float mu, float wd, float gscale, int first) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 pv = p[i], gv = g[i], mv;
+        gv.x = gv.x * gscale + wd * pv.x;
+        gv.y = gv.y * gscale + wd * pv.y;
+        gv.z = gv.z * gscale + wd * pv.z;
+        gv.w = gv.w * gscale + wd * pv.w;
+        if (first) {
+            mv = gv;
+        } else {
+            mv = m[i];
+            mv.x = mu * mv.x + gv.x;
+            mv.y = mu * mv.y + gv.y;
+            mv.z = mu * mv.z + gv.z;
+            mv.w = mu * mv.w + gv.w;
+        }
+        pv.x -= lr * mv.x;
+        pv.y -= lr * mv.y;
+        pv.z -= lr * mv.z;
+        pv.w -= lr * mv.w;
+        m[i] = mv;
+        p[i] = pv;
+        if (shadow) {
+            uint2 s;
+            s.x = pack2(pv.x, pv.y);
+            s.y = pack2(pv.z, pv.w);
+            shadow[i] = s;
+        }
+    }
+}
+
+void sgd_momentum(float* p, const float* g, float* m, bf16_raw* shadow, size_t n, float lr,
+                  float mu, float wd, float grad_scale, bool first_step, hipStream_t stream) {
+    if (n % 4 != 0) throw std::invalid_argument("sgd_momentum: n must be a multiple of 4");
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m) & 15)
+        throw std::invalid_argument("sgd_momentum: buffers must be 16-byte aligned");
+    if (n == 0) return;
+    const size_t n4 = n / 4;
+    const int block = 256;
+    size_t blocks = (n4 + block - 1) / block;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)blocks), dim3(block), 0, stream,
+                       (float4*)p, (const float4*)g, (float4*)m, (uint2*)shadow, n4, lr, mu, wd,
+                       grad_scale, first_step ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void cast_f32_to_bf16_kernel(const float4* __restrict__ x,
+                                                               uint2* __restrict__ out, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        const float4 v = x[i];
+        uint2 o;
+        o.x = pack2(v.x, v.y);
+        o.y = pack2(v.z, v.w);
+        out[i] = o;
+    }
+}
+
+void cast_f32_to_bf16(const float* x, bf16_raw* out, size_t n, hipStream_t stream) {
+    if (n % 4 != 0) throw std::invalid_argument("cast_f32_to_bf16: n must be a multiple of 4");
+    if (n == 0) return;
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       (const float4*)x, (uint2*)out, n4);
+}
+
+// ---------------------------------------------------------------------------- linear
+// out_features <= 16 (10 here): far too narrow for MFMA tiles.  One wave per batch row;
+// each lane owns a contiguous slice of K, keeps `out_features` partial dots in registers
+// and the wave reduces them with xor-shuffles.
+template <int NOUT>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(
+    const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ logits, int batch, int k, int nout) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= batch) return;
+    float acc[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+    for (int k0 = lane * 8; k0 < k; k0 += 64 * 8) {
+        float xv[8];
+        unpack8(*(const uint4*)(x + (size_t)row * k + k0), xv);
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            if (n < nout) {
+                const float4 w0 = *(const float4*)(w + (size_t)n * k + k0);
+                const float4 w1 = *(const float4*)(w + (size_t)n * k + k0 + 4);
+                acc[n] += xv[0] * w0.x + xv[1] * w0.y + xv[2] * w0.z + xv[3] * w0.w +
+                          xv[4] * w1.x + xv[5] * w1.y + xv[6] * w1.z + xv[7] * w1.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+        const float s = wave_sum(acc[n]);
+        if (lane == 0 && n < nout) logits[(size_t)row * nout + n] = s + bias[n];
+    }
+}
+
+void linear_fwd(const bf16_raw* x, const float* w, const float* bias, float* logits, int batch,
+                int in_features, int out_features, hipStream_t stream) {
+    if (out_features < 1 || out_features > 16)
+        throw std::invalid_argument("linear_fwd: out_features must be in [1,16]");
+    if (in_features % 8 != 0) throw std::invalid_argument("linear_fwd: in_features % 8 != 0");
+    if (batch <= 0) return;
+    hipLaunchKernelGGL(linear_fwd_kernel<16>, dim3((batch + 3) / 4), dim3(256), 0, stream, x, w,
+                       bias, logits, batch, in_features, out_features);
+}
+
+// dx[b][k] = sum_n dl[b][n] w[n][k]: one thread per (b, 8 k's).
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(
+    const float* __restrict__ w, const float* __restrict__ dl, uint16_t* __restrict__ dx,
+    int batch, int k, int nout) {
+    const int kc = k / 8;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)batch * kc) return;
+    const int b = (int)(idx / kc), k0 = (int)(idx % kc) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int n = 0; n < nout; ++n) {
+        const float d = dl[(size_t)b * nout + n];
+        const float4 w0 = *(const float4*)(w + (size_t)n * k + k0);
+        const float4 w1 = *(const float4*)(w + (size_t)n * k + k0 + 4);
+        acc[0] += d * w0.x; acc[1] += d * w0.y; acc[2] += d * w0.z; acc[3] += d * w0.w;
+        acc[4] += d * w1.x; acc[5] += d * w1.y; acc[6] += d * w1.z; acc[7] += d * w1.w;
+    }
+    *(uint4*)(dx + (size_t)b * k + k0) = pack8(acc);
+}
+
+// dw[n][k] = sum_b dl[b][n] x[b][k]; db[n] = sum_b dl[b][n].  One thread per (n, k); the
+// batch loop reads x coalesced across k and dl as a broadcast.
+__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(
+    const uint16_t* __restrict__ x, const float* __restrict__ dl, float* __restrict__ dw,
+    float* __restrict__ db, int batch, int k, int nout) {
+    const int kk = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (kk >= k) return;
+    float acc = 0.f, accb = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        const float d = dl[(size_t)b * nout + n];
+        acc += d * bf16_bits_to_float(x[(size_t)b * k + kk]);
+        accb += d;
+    }
+    dw[(size_t)n * k + kk] = acc;
+    if (kk == 0) db[n] = accb;
+}
+
+void linear_bwd(const bf16_raw* x, const float* w, const float* dlogits, float* dw, float* db,
+                bf16_raw* dx, int batch, int in_features, int out_features, hipStream_t stream) {
+    if (in_features % 8 != 0) throw std::invalid_argument("linear_bwd: in_features % 8 != 0");
+    if (batch <= 0) return;
+    if (dx) {
+        const size_t total = (size_t)batch * (in_features / 8);
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                           0, stream, w, dlogits, dx, batch, in_features, out_features);
+    }
+    if (dw) {
+        hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((in_features + 255) / 256, out_features),
+                           dim3(256), 0, stream, x, dlogits, dw, db, batch, in_features,
+                           out_features);
+    }
+}
+
+// --------------------------------------------------------------- softmax cross-entropy
+// One thread per row (classes <= 32): max, sum-exp, loss, gradient and arg-max in
+// registers; the per-block loss / correct partials are wave-reduced, then one atomic each.
+__global__ __launch_bounds__(256) void softmax_xent_kernel(
+    const float* __restrict__ logits, const int64_t* __restrict__ target,
+    float* __restrict__ loss_sum, float* __restrict__ dlogits, int32_t* __restrict__ correct,
+    int batch, int classes, float inv_batch, float gscale) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    float loss = 0.f;
+    int ok = 0;
+    if (row < batch) {
+        const float* l = logits + (size_t)row * classes;
+        const int t = (int)target[row];
+        float mx = l[0];
+        int arg = 0;
+        for (int c = 1; c < classes; ++c) {
+            const float v = l[c];
+            if (v > mx) { mx = v; arg = c; }
+        }
+        float se = 0.f;
+        for (int c = 0; c < classes; ++c) se += __expf(l[c] - mx);
+        const float lse = mx + __logf(se);
+        loss = (lse - l[t]) * inv_batch;
+        ok = (arg == t) ? 1 : 0;
+        if (dlogits) {
+            const float inv = 1.f / se;
+            for (int c = 0; c < classes; ++c) {
+                const float pr = __expf(l[c] - mx) * inv;
+                dlogits[(size_t)row * classes + c] = (pr - (c == t ? 1.f : 0.f)) * inv_batch * gscale;
+            }
+        }
+    }
+    loss = wave_sum(loss);
+    float okf = wave_sum((float)ok);
+    if ((threadIdx.x & 63) == 0) {
+        if (loss_sum) atomicAdd(loss_sum, loss);
+        if (correct && okf != 0.f) atomicAdd(correct, (int)(okf + 0.5f));
+    }
+}
+
+void softmax_xent(const float* logits, const int64_t* target, float* loss_sum, float* dlogits,
+                  int32_t* correct, int batch, int classes, float grad_scale, hipStream_t stream) {
+    if (classes < 1 || classes > 1024) throw std::invalid_argument("softmax_xent: bad class count");
+    if (batch <= 0) return;
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, logits,
+                       target, loss_sum, dlogits, correct, batch, classes, 1.0f / (float)batch,
+                       grad_scale);
+}
+
+}  // namespace dml

@@ -1,0 +1,289 @@
+// Max-pool 2x2 (NHWC bf16), column sums, data preparation and layout conversion.
+//
+// Reference call sites: nn.MaxPool2d(kernel_size=2, stride=2)
+// (/root/reference/part1/model.py:16); the torchvision transform pipeline
+// RandomCrop(32, padding=4) / RandomHorizontalFlip / ToTensor / Normalize
+// (/root/reference/part1/main.py:84-93); the root-side gradient sum of the
+// gather/scatter mode (/root/reference/part2/2a/main.py:104-107).
+//
+// All of these are memory-bound: every thread moves 16-byte vectors (8 bf16 channels).
+#include <stdexcept>
+
+#include "dml_common.h"
+#include "dml_kernels.h"
+
+namespace dml {
+
+__device__ __forceinline__ void max8(float (&m)[8], const float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], v[i]);
+}
+
+// ---------------------------------------------------------------------- maxpool fwd
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const uint16_t* __restrict__ x,
+                                                          uint16_t* __restrict__ y, int hw, int c,
+                                                          size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = c / 8, ohw = hw / 2;
+    const int cc = (int)(idx % c8);
+    size_t r = idx / c8;
+    const int ow = (int)(r % ohw); r /= ohw;
+    const int oh = (int)(r % ohw);
+    const size_t b = r / ohw;
+    const uint16_t* src = x + (((b * hw + 2 * oh) * hw + 2 * ow) * c) + cc * 8;
+    float m[8], v[8];
+    unpack8(*(const uint4*)src, m);
+    unpack8(*(const uint4*)(src + c), v); max8(m, v);
+    unpack8(*(const uint4*)(src + (size_t)hw * c), v); max8(m, v);
+    unpack8(*(const uint4*)(src + (size_t)hw * c + c), v); max8(m, v);
+    *(uint4*)(y + idx * 8) = pack8(m);
+}
+
+void maxpool2x2_fwd(const bf16_raw* x, bf16_raw* y, int batch, int hw, int c, hipStream_t stream) {
+    if (hw < 2 || (hw & 1) || c % 8) throw std::invalid_argument("maxpool2x2_fwd: bad shape");
+    const size_t total = (size_t)batch * (hw / 2) * (hw / 2) * (c / 8);
+    if (total == 0) return;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       stream, x, y, hw, c, total);
+}
+
+// ---------------------------------------------------------------------- maxpool bwd
+// One thread per pooled position x 8 channels: re-derives the arg-max from the saved
+// input (first maximum in row-major window order, like the index the forward of a
+// framework pool records), writes all four input positions (zeros off the route).
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint16_t* __restrict__ x,
+                                                          const uint16_t* __restrict__ dy,
+                                                          uint16_t* __restrict__ dx, int hw, int c,
+                                                          size_t total, int relu_mask) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = c / 8, ohw = hw / 2;
+    const int cc = (int)(idx % c8);
+    size_t r = idx / c8;
+    const int ow = (int)(r % ohw); r /= ohw;
+    const int oh = (int)(r % ohw);
+    const size_t b = r / ohw;
+    const size_t base = (((b * hw + 2 * oh) * hw + 2 * ow) * c) + cc * 8;
+    const size_t off[4] = {0, (size_t)c, (size_t)hw * c, (size_t)hw * c + c};
+    float v[4][8], g[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) unpack8(*(const uint4*)(x + base + off[q]), v[q]);
+    unpack8(*(const uint4*)(dy + idx * 8), g);
+    float o[4][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int arg = 0;
+        float m = v[0][i];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (v[q][i] > m) { m = v[q][i]; arg = q; }
+        const float gi = (relu_mask && !(m > 0.f)) ? 0.f : g[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q][i] = (q == arg) ? gi : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(uint4*)(dx + base + off[q]) = pack8(o[q]);
+}
+
+void maxpool2x2_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, int batch, int hw, int c,
+                    bool relu_mask, hipStream_t stream) {
+    if (hw < 2 || (hw & 1) || c % 8) throw std::invalid_argument("maxpool2x2_bwd: bad shape");
+    const size_t total = (size_t)batch * (hw / 2) * (hw / 2) * (c / 8);
+    if (total == 0) return;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       stream, x, dy, dx, hw, c, total, relu_mask ? 1 : 0);
+}
+
+// ----------------------------------------------------------------------- column sum
+// out[c] += sum over rows.  Block = 256 threads = (256 / (c/8)) row lanes x (c/8) column
+// groups; each block walks a strided slab of rows, reduces across its row lanes in LDS and
+// issues one atomic per column.
+__global__ __launch_bounds__(256) void column_sum_kernel(const uint16_t* __restrict__ x,
+                                                         float* __restrict__ out, int rows, int c,
+                                                         int rows_per_block) {
+    __shared__ float red[256 * 8];
+    const int c8 = c / 8;                 // 8 .. 64 column groups
+    const int lanes = 256 / c8;           // row lanes per block
+    const int cg = threadIdx.x % c8, rl = threadIdx.x / c8;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (rl < lanes) {
+        for (int r = r0 + rl; r < r1; r += lanes) {
+            float v[8];
+            unpack8(*(const uint4*)(x + (size_t)r * c + cg * 8), v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = (rl < lanes) ? acc[i] : 0.f;
+    __syncthreads();
+    // thread t < c sums column t over the row lanes
+    for (int col = threadIdx.x; col < c; col += 256) {
+        const int g = col / 8, i = col % 8;
+        float s = 0.f;
+        for (int l = 0; l < lanes; ++l) s += red[(l * c8 + g) * 8 + i];
+        atomicAdd(out + col, s);
+    }
+}
+
+void column_sum(const bf16_raw* x, float* out, int rows, int cols, hipStream_t stream) {
+    if (cols % 8 || cols < 8 || cols > 2048 || (256 % (cols / 8)) != 0)
+        throw std::invalid_argument("column_sum: cols must be 8*2^k, <= 2048");
+    if (rows <= 0) return;
+    int blocks = (rows + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    const int rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(column_sum_kernel, dim3(blocks), dim3(256), 0, stream, x, out, rows, cols,
+                       rpb);
+}
+
+// ------------------------------------------------------------- augmentation + normalise
+// One thread per output pixel: crop/flip source lookup on the uint8 HWC image, zero padding
+// applied before normalisation, 8-byte bf16 NHWC4 store.
+struct Norm3 { float mean[3]; float inv_std[3]; };
+
+__global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict__ img,
+                                                      const int32_t* __restrict__ aug,
+                                                      uint16_t* __restrict__ out, size_t total,
+                                                      Norm3 nm) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int xo = (int)(idx & 31), yo = (int)((idx >> 5) & 31);
+    const size_t b = idx >> 10;
+    int sy = yo, sx = xo;
+    if (aug) {
+        const int oy = aug[b * 3], ox = aug[b * 3 + 1], fl = aug[b * 3 + 2];
+        sy = yo + oy - 4;
+        sx = (fl ? 31 - xo : xo) + ox - 4;
+    }
+    float v[3] = {0.f, 0.f, 0.f};
+    if ((unsigned)sy < 32u && (unsigned)sx < 32u) {
+        const uint8_t* p = img + ((b * 32 + sy) * 32 + sx) * 3;
+        v[0] = p[0] * (1.f / 255.f); v[1] = p[1] * (1.f / 255.f); v[2] = p[2] * (1.f / 255.f);
+    }
+    uint2 o;
+    o.x = pack2((v[0] - nm.mean[0]) * nm.inv_std[0], (v[1] - nm.mean[1]) * nm.inv_std[1]);
+    o.y = pack2((v[2] - nm.mean[2]) * nm.inv_std[2], 0.f);
+    *(uint2*)(out + idx * 4) = o;
+}
+
+void augment_normalize(const uint8_t* images, const int32_t* aug, bf16_raw* out, int batch,
+                       const float mean[3], const float stdv[3], hipStream_t stream) {
+    if (batch <= 0) return;
+    Norm3 nm;
+    for (int i = 0; i < 3; ++i) { nm.mean[i] = mean[i]; nm.inv_std[i] = 1.f / stdv[i]; }
+    const size_t total = (size_t)batch * 1024;
+    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       images, aug, out, total, nm);
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x,
+                                                            uint16_t* __restrict__ out,
+                                                            size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const size_t b = idx >> 10, pix = idx & 1023;
+    const float* p = x + b * 3072 + pix;
+    uint2 o;
+    o.x = pack2(p[0], p[1024]);
+    o.y = pack2(p[2048], 0.f);
+    *(uint2*)(out + idx * 4) = o;
+}
+
+void nchw_to_nhwc4(const float* x, bf16_raw* out, int batch, hipStream_t stream) {
+    if (batch <= 0) return;
+    const size_t total = (size_t)batch * 1024;
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       stream, x, out, total);
+}
+
+// Generic layout converters (tests, eager API boundary; not on the training hot path).
+__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ x,
+                                                                    uint16_t* __restrict__ out,
+                                                                    int c, int hw2, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over NHWC elements
+    if (idx >= total) return;
+    const int ch = (int)(idx % c);
+    const size_t r = idx / c;
+    const int pix = (int)(r % hw2);
+    const size_t b = r / hw2;
+    out[idx] = float_to_bf16_bits(x[(b * c + ch) * hw2 + pix]);
+}
+
+__global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const uint16_t* __restrict__ x,
+                                                                    float* __restrict__ out,
+                                                                    int c, int hw2, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over NCHW elements
+    if (idx >= total) return;
+    const int pix = (int)(idx % hw2);
+    const size_t r = idx / hw2;
+    const int ch = (int)(r % c);
+    const size_t b = r / c;
+    out[idx] = bf16_bits_to_float(x[(b * hw2 + pix) * c + ch]);
+}
+
+void nchw_f32_to_nhwc_bf16(const float* x, bf16_raw* out, int batch, int c, int hw, hipStream_t s) {
+    const size_t total = (size_t)batch * c * hw * hw;
+    if (total == 0) return;
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3((unsigned)((total + 255) / 256)),
+                       dim3(256), 0, s, x, out, c, hw * hw, total);
+}
+
+void nhwc_bf16_to_nchw_f32(const bf16_raw* x, float* out, int batch, int c, int hw, hipStream_t s) {
+    const size_t total = (size_t)batch * c * hw * hw;
+    if (total == 0) return;
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)),
+                       dim3(256), 0, s, x, out, c, hw * hw, total);
+}
+
+// ---------------------------------------------------------------- W-way slab reduction
+__global__ __launch_bounds__(256) void sum_slabs_kernel(float4* __restrict__ slabs, int world,
+                                                        size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 a = slabs[i];
+        for (int r = 1; r < world; ++r) {
+            const float4 v = slabs[(size_t)r * n4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        slabs[i] = a;
+    }
+}
+
+void sum_slabs(float* slabs, int world, size_t n, hipStream_t stream) {
+    if (n % 4) throw std::invalid_argument("sum_slabs: n must be a multiple of 4");
+    if (world <= 1 || n == 0) return;
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       (float4*)slabs, world, n4);
+}
+
+// ------------------------------------------------------------------- deterministic fill
+__global__ __launch_bounds__(256) void fill_uniform_kernel(uint16_t* __restrict__ out, size_t n,
+                                                           uint32_t seed, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t h = (uint32_t)i * 0x9E3779B1u ^ seed;
+        h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+        const float u = (float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;   // [-1, 1)
+        out[i] = float_to_bf16_bits(u * scale);
+    }
+}
+
+void fill_uniform_bf16(bf16_raw* out, size_t n, uint32_t seed, float scale, hipStream_t stream) {
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out, n,
+                       seed, scale);
+}
+
+}  // namespace dml

@@ -1,0 +1,215 @@
+"""Native execution backend: the C++ ``VggEngine`` plus the RCCL sync strategies.
+
+One training step = ``engine.forward_backward`` (zero_grad, forward, loss, backward with
+the bucket reducer's hooks) -> manual sync strategy if selected -> ``engine.optimizer_step``
+(reducer wait, fused SGD, bf16 weight shadows), all enqueued on torch's current stream;
+the reference's equivalent sequence is /root/reference/part2/2b/main.py:52-62.
+
+Flat buffers are torch tensors so parameters can be viewed, broadcast, checkpointed and
+compared against the stock-torch model; their internal layout (conv weights
+``[cout,3,3,cin]``) is converted to the OIHW ``state_dict`` contract at the boundary.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from ..config import SYNC_ALL_REDUCE, SYNC_DDP, SYNC_GATHER_SCATTER, SYNC_NONE, TrainConfig
+from ..models.vgg import VGG, VGG_WIDTHS
+from ..ops import native
+from ..parallel.comm import Communicator
+from ..parallel.strategies import AllReduceSync, GatherScatterSync, GradSync, NoSync
+
+
+class NativeBackend:
+    name = "native"
+    loader_layout = "nhwc4_bf16"
+
+    def __init__(self, cfg: TrainConfig, device: torch.device, comm: Optional[Communicator],
+                 init_state: Optional[Dict[str, torch.Tensor]] = None):
+        if cfg.dtype not in ("bf16", "auto"):
+            raise NotImplementedError(
+                "the native engine computes in bf16 with fp32 master weights, accumulators and "
+                "statistics; use --backend torch for an all-fp32 run")
+        self.cfg = cfg
+        self.device = device
+        self.comm = comm
+        self.world = comm.world_size if comm is not None else 1
+        C = native.lib()
+        widths = [-1 if w == "M" else int(w) for w in VGG_WIDTHS[cfg.arch]]
+        self.engine = C.VggEngine(widths, cfg.batch_size, cfg.batch_norm, cfg.num_classes)
+        e = self.engine
+        f32 = dict(dtype=torch.float32, device=device)
+        self.params = torch.zeros(e.param_elems, **f32)
+        self.grads = torch.zeros(e.param_elems, **f32)
+        self.momentum = torch.zeros(e.param_elems, **f32)
+        self.bn_buffers = torch.zeros(max(e.bn_elems, 1), **f32)
+        self.arena = torch.zeros(e.arena_elems, dtype=torch.bfloat16, device=device)
+        self.workspace = torch.zeros(e.workspace_elems, **f32)
+        e.bind(self.params.data_ptr(), self.grads.data_ptr(), self.momentum.data_ptr(),
+               self.bn_buffers.data_ptr() if cfg.batch_norm else 0, self.arena.data_ptr(),
+               self.workspace.data_ptr())
+        self.slots = list(e.param_slots)
+        self.buffer_slots = list(e.buffer_slots)
+        self._loss_off = e.loss_offset
+        self._training = True
+        # initial weights: the stock module's initialisers under the caller's seed, so every
+        # backend (and every rank) starts from the same numbers the reference would
+        if init_state is None:
+            init_state = VGG(cfg.arch, cfg.batch_norm, cfg.num_classes).state_dict()
+        self.load_state_dict(init_state)
+        self.reducer = None
+        self.sync = self._build_sync()
+        self._graph_ready = False
+        self._x_static = None
+        self._t_static = None
+
+    # ------------------------------------------------------------------ sync
+    def _grad_views(self) -> List[torch.Tensor]:
+        return [self.grads[s.offset:s.offset + s.numel] for s in self.slots]
+
+    def _build_sync(self) -> GradSync:
+        cfg, comm = self.cfg, self.comm
+        reduce = cfg.resolved_grad_reduce()
+        if cfg.sync == SYNC_NONE or comm is None:
+            return NoSync(comm, reduce)
+        if cfg.sync == SYNC_GATHER_SCATTER:
+            return GatherScatterSync(comm, self._grad_views(), reduce)
+        if cfg.sync == SYNC_ALL_REDUCE:
+            return AllReduceSync(comm, self._grad_views(), reduce)
+        if cfg.sync == SYNC_DDP:
+            C = native.lib()
+            sizes = [s.numel * 4 for s in self.slots]
+            buckets = C.plan_buckets(sizes, int(cfg.bucket_cap_mb * (1 << 20)), 1 << 20)
+            slices = []
+            for lo, hi in buckets:
+                start = self.slots[lo].offset
+                end = self.slots[hi - 1].offset + self.slots[hi - 1].numel
+                slices.append((start, end - start))
+            self.buckets = buckets
+            self.reducer = C.BucketReducer(comm.native, self.grads.data_ptr(), slices,
+                                           reduce == "mean", cfg.serialize_streams)
+            self.engine.set_reducer(self.reducer, buckets)
+            # what DistributedDataParallel's constructor does: everyone adopts rank 0's state
+            if self.world > 1:
+                comm.broadcast(self.params, 0)
+                if cfg.batch_norm:
+                    comm.broadcast(self.bn_buffers, 0)
+                self.engine.refresh_weights(self._stream())
+            return NoSync(comm, reduce)
+        raise ValueError(cfg.sync)
+
+    # ------------------------------------------------------------------ steps
+    @staticmethod
+    def _stream() -> int:
+        return int(torch.cuda.current_stream().cuda_stream)
+
+    def train_mode(self, on: bool = True) -> None:
+        self._training = on
+
+    def _check_batch(self, data: torch.Tensor, target: torch.Tensor) -> int:
+        if data.dtype != torch.bfloat16 or data.dim() != 4 or tuple(data.shape[1:]) != (32, 32, 4):
+            raise ValueError(f"native backend expects bf16 [B,32,32,4] input, got "
+                             f"{data.dtype} {tuple(data.shape)}")
+        n = int(data.shape[0])
+        if n > self.cfg.batch_size or target.shape[0] != n or target.dtype != torch.int64:
+            raise ValueError("batch larger than the engine was built for, or bad target")
+        if not (data.is_contiguous() and target.is_contiguous()):
+            raise ValueError("inputs must be contiguous")
+        return n
+
+    def train_step(self, data: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        cfg, e = self.cfg, self.engine
+        n = self._check_batch(data, target)
+        s = self._stream()
+        if cfg.use_graph and self.world == 1:
+            return self._train_step_graph(data, target, n, s)
+        if self.reducer is not None and cfg.batch_norm and cfg.broadcast_buffers \
+                and self.world > 1:
+            self.comm.broadcast(self.bn_buffers, 0)     # DDP's per-forward buffer broadcast
+        e.forward_backward(data.data_ptr(), target.data_ptr(), n, s)
+        self.sync.finish()
+        e.optimizer_step(cfg.lr, cfg.momentum, cfg.weight_decay, 1.0, s)
+        return self.workspace[self._loss_off:self._loss_off + 1]
+
+    def _train_step_graph(self, data, target, n, s):
+        cfg, e = self.cfg, self.engine
+        if n != cfg.batch_size:
+            raise ValueError("graph mode needs full batches")
+        if not self._graph_ready:
+            self._x_static = torch.empty_like(data)
+            self._t_static = torch.empty_like(target)
+        self._x_static.copy_(data)
+        self._t_static.copy_(target)
+        if not self._graph_ready:
+            e.capture_train_step(self._x_static.data_ptr(), self._t_static.data_ptr(), n, cfg.lr,
+                                 cfg.momentum, cfg.weight_decay, 1.0, s)
+            self._graph_ready = True
+        e.replay_train_step(s)
+        return self.workspace[self._loss_off:self._loss_off + 1]
+
+    @torch.no_grad()
+    def eval_batch(self, data: torch.Tensor, target: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        n = self._check_batch(data, target)
+        lo = self._loss_off
+        self.workspace[lo + 1:lo + 3].zero_()
+        self.engine.eval_step(data.data_ptr(), target.data_ptr(), n, self._stream())
+        loss = self.workspace[lo + 1].clone()
+        correct = self.workspace[lo + 2:lo + 3].view(torch.int32)[0].clone()
+        return loss, correct
+
+    def logits(self, n: int) -> torch.Tensor:
+        off = self.engine.logits_offset
+        c = self.cfg.num_classes
+        return self.workspace[off:off + n * c].view(n, c)
+
+    # ------------------------------------------------------------ state dict
+    def _param_view(self, slot) -> torch.Tensor:
+        return self.params[slot.offset:slot.offset + slot.numel].view(*slot.shape)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Reference layout: conv weights OIHW fp32, BatchNorm buffers included."""
+        out: Dict[str, torch.Tensor] = {}
+        bufs = {s.name: s for s in self.buffer_slots}
+        for slot in self.slots:
+            v = self._param_view(slot)
+            if len(slot.shape) == 4:
+                v = v.permute(0, 3, 1, 2)
+            out[slot.name] = v.detach().clone().contiguous()
+            if self.cfg.batch_norm and slot.name.endswith(".bias") and \
+                    slot.name.replace(".bias", ".running_mean") in bufs:
+                base = slot.name[:-len(".bias")]
+                for leaf in ("running_mean", "running_var"):
+                    b = bufs[f"{base}.{leaf}"]
+                    out[f"{base}.{leaf}"] = self.bn_buffers[b.offset:b.offset + b.numel].clone()
+                out[f"{base}.num_batches_tracked"] = torch.tensor(
+                    int(self.engine.bn_steps), dtype=torch.int64, device=self.device)
+        return out
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        from ..models.checkpoint import strip_ddp_prefix, validate_state_dict
+        sd = strip_ddp_prefix(sd)
+        validate_state_dict(sd, self.cfg.arch, self.cfg.batch_norm)
+        for slot in self.slots:
+            src = sd[slot.name].to(device=self.device, dtype=torch.float32)
+            if len(slot.shape) == 4:
+                src = src.permute(0, 2, 3, 1)
+            self._param_view(slot).copy_(src)
+        steps = 0
+        for b in self.buffer_slots:
+            self.bn_buffers[b.offset:b.offset + b.numel].copy_(
+                sd[b.name].to(device=self.device, dtype=torch.float32))
+            steps = int(sd[b.name.rsplit(".", 1)[0] + ".num_batches_tracked"])
+        self.engine.bn_steps = steps
+        self.momentum.zero_()
+        self.engine.refresh_weights(self._stream())
+
+    def parameters_flat(self) -> torch.Tensor:
+        return self.params
+
+    def close(self) -> None:
+        torch.cuda.synchronize()
+        self.engine.set_reducer(None, [])
+        self.reducer = None

@@ -106,6 +106,8 @@ class Trainer:
                 value = float(loss.item())
                 self.losses[batch_idx + 1] = value
                 print(f"Loss at {batch_idx+1}th batch is {value}")
+            if self.comm is not None and self.world > 1:
+                self.comm.guard_sync(cfg.comm_timeout_s)
             timer.stop()
         denom = max(cfg.iters - 1, 1)
         colon = " " * cfg.avg_colon_spaces + ":"

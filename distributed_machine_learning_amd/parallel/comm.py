@@ -68,6 +68,10 @@ class Communicator:
     def group_start(self) -> None:      # lets a transport fuse a run of calls into one launch
         pass
 
+    def guard_sync(self, timeout_s: float = 300.0) -> None:
+        """Wait for enqueued work with a deadline (turns a lost peer into an error)."""
+        pass
+
     def group_end(self) -> None:
         pass
 
@@ -188,7 +192,7 @@ class RcclCommunicator(Communicator):
         else:
             uid = self._store.get(key)
         # nobody may tear the server down before every rank has read the id
-        self._store.barrier("uid_read", rank)
+        self._store.barrier("uid_read")
         return uid
 
     # -- helpers -----------------------------------------------------------------
@@ -246,6 +250,9 @@ class RcclCommunicator(Communicator):
         token = torch.zeros(1, device=f"cuda:{self.device_index}")
         self.all_reduce(token)
         torch.cuda.current_stream().synchronize()
+
+    def guard_sync(self, timeout_s: float = 300.0) -> None:
+        self._comm.wait_stream(self._stream(), float(timeout_s))
 
     def group_start(self):
         self._comm.group_start()

@@ -70,7 +70,8 @@ class GatherScatterSync(GradSync):
         self.slabs = None
         if self.is_root:
             total = sum(g.numel() for g in self.grads)
-            self._slab_store = torch.empty(w, total, dtype=self.grads[0].dtype,
+            total = (total + 3) // 4 * 4        # the slab-sum kernel moves 16-byte vectors
+            self._slab_store = torch.zeros(w, total, dtype=self.grads[0].dtype,
                                            device=self.grads[0].device)
             self.slabs, off = [], 0
             for g in self.grads:

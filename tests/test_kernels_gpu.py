@@ -1,0 +1,261 @@
+"""Numerics of every HIP kernel against a plain PyTorch fp32 reference of the same op.
+
+Inputs are bf16-representable values; references are computed in fp32 from exactly
+those values, so the only differences are accumulation order and the final bf16 rounding
+of bf16 outputs (relative 2^-8).  Shapes cover the eight VGG-11 conv layers.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+# (cin, cout, hw) of VGG-11 conv2..conv8 (conv1 has its own kernels)
+GENERIC_LAYERS = [(64, 128, 16), (128, 256, 8), (256, 256, 8), (256, 512, 4), (512, 512, 4),
+                  (512, 512, 2)]
+
+
+def native():
+    from distributed_machine_learning_amd.ops import native as n
+    n.lib()
+    return n
+
+
+def rand_bf16(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+def nchw(x_nhwc):
+    return x_nhwc.float().permute(0, 3, 1, 2).contiguous()
+
+
+def oihw(w_krsc):
+    return w_krsc.float().permute(0, 3, 1, 2).contiguous()
+
+
+def check(name, got, ref, rtol=1.5e-2, atol_scale=1.5e-2):
+    got = got.float()
+    ref = ref.float()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    scale = float(ref.abs().max().clamp_min(1e-6))
+    err = (got - ref).abs()
+    tol = atol_scale * scale * 0.25 + rtol * ref.abs()
+    bad = err > tol
+    if bool(bad.any()):
+        idx = bad.nonzero()[:5].tolist()
+        raise AssertionError(
+            f"{name}: {int(bad.sum())}/{bad.numel()} elements off; max err {float(err.max()):.4g} "
+            f"(ref scale {scale:.4g}); first bad idx {idx}; got {got[bad][:5].tolist()} "
+            f"ref {ref[bad][:5].tolist()}")
+
+
+@pytest.mark.parametrize("batch", [2, 32])
+@pytest.mark.parametrize("cin,cout,hw", GENERIC_LAYERS)
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3x3_fwd(batch, cin, cout, hw, relu):
+    n = native()
+    x = rand_bf16(batch, hw, hw, cin, seed=1)
+    w = rand_bf16(cout, 3, 3, cin, scale=(2.0 / (9 * cin)) ** 0.5, seed=2)
+    b = torch.randn(cout, device=DEV) * 0.1
+    y = n.conv3x3_fwd(x, w, b, relu=relu)
+    ref = F.conv2d(nchw(x), oihw(w), b, padding=1)
+    if relu:
+        ref = ref.relu()
+    check(f"fwd {cin}->{cout}@{hw} B{batch}", nchw(y), ref)
+
+
+def test_conv3x3_fwd_b256_conv4_and_conv8():
+    n = native()
+    for cin, cout, hw in [(256, 256, 8), (512, 512, 2), (64, 128, 16)]:
+        x = rand_bf16(256, hw, hw, cin, seed=3)
+        w = rand_bf16(cout, 3, 3, cin, scale=(2.0 / (9 * cin)) ** 0.5, seed=4)
+        b = torch.randn(cout, device=DEV) * 0.1
+        y = n.conv3x3_fwd(x, w, b, relu=True)
+        ref = F.conv2d(nchw(x), oihw(w), b, padding=1).relu()
+        check(f"fwd {cin}->{cout}@{hw} B256", nchw(y), ref)
+
+
+@pytest.mark.parametrize("batch", [2, 32])
+@pytest.mark.parametrize("cin,cout,hw", GENERIC_LAYERS)
+def test_conv3x3_dgrad(batch, cin, cout, hw):
+    n = native()
+    dy = rand_bf16(batch, hw, hw, cout, seed=5)
+    w = rand_bf16(cout, 3, 3, cin, scale=(2.0 / (9 * cout)) ** 0.5, seed=6)
+    wd = n.repack_dgrad(w)
+    # repack is exact
+    ref_wd = w.float().flip(1, 2).permute(3, 1, 2, 0).contiguous()
+    assert torch.equal(wd.float(), ref_wd), "repack_dgrad mismatch"
+    dx = n.conv3x3_dgrad(dy, wd)
+    ref = torch.nn.grad.conv2d_input((batch, cin, hw, hw), oihw(w), nchw(dy), padding=1)
+    check(f"dgrad {cout}->{cin}@{hw} B{batch}", nchw(dx), ref)
+    # fused ReLU backward
+    act = rand_bf16(batch, hw, hw, cin, seed=7).relu()
+    dxm = n.conv3x3_dgrad(dy, wd, relu_mask=act)
+    check(f"dgrad+mask {cout}->{cin}@{hw} B{batch}", nchw(dxm), ref * (nchw(act) > 0))
+
+
+@pytest.mark.parametrize("batch", [2, 32])
+@pytest.mark.parametrize("cin,cout,hw", GENERIC_LAYERS)
+def test_conv3x3_wgrad(batch, cin, cout, hw):
+    n = native()
+    x = rand_bf16(batch, hw, hw, cin, seed=8)
+    dy = rand_bf16(batch, hw, hw, cout, seed=9)
+    dw = n.conv3x3_wgrad(x, dy)
+    ref = torch.nn.grad.conv2d_weight(nchw(x), (cout, cin, 3, 3), nchw(dy), padding=1)
+    check(f"wgrad {cin}->{cout}@{hw} B{batch}", dw.permute(0, 3, 1, 2), ref, rtol=2e-3,
+          atol_scale=2e-3)
+
+
+def test_conv3x3_wgrad_b256():
+    n = native()
+    for cin, cout, hw in [(64, 128, 16), (512, 512, 2)]:
+        x = rand_bf16(256, hw, hw, cin, seed=10)
+        dy = rand_bf16(256, hw, hw, cout, seed=11)
+        dw = n.conv3x3_wgrad(x, dy)
+        ref = torch.nn.grad.conv2d_weight(nchw(x), (cout, cin, 3, 3), nchw(dy), padding=1)
+        check(f"wgrad {cin}->{cout}@{hw} B256", dw.permute(0, 3, 1, 2), ref, rtol=2e-3,
+              atol_scale=2e-3)
+
+
+@pytest.mark.parametrize("batch", [2, 64, 256])
+def test_conv1_fwd_and_wgrad(batch):
+    n = native()
+    x3 = rand_bf16(batch, 32, 32, 3, seed=12)
+    x4 = torch.zeros(batch, 32, 32, 4, dtype=torch.bfloat16, device=DEV)
+    x4[..., :3] = x3
+    w = (torch.randn(64, 3, 3, 3, device=DEV) * 0.2).to(torch.bfloat16).float()
+    b = torch.randn(64, device=DEV) * 0.1
+    w1 = n.pack_conv1_weights(w)
+    y = n.conv1_fwd(x4, w1, b, relu=True)
+    ref = F.conv2d(nchw(x3), w.permute(0, 3, 1, 2).contiguous(), b, padding=1).relu()
+    check(f"conv1 fwd B{batch}", nchw(y), ref)
+    dy = rand_bf16(batch, 32, 32, 64, seed=13)
+    dw, db = n.conv1_wgrad(x4, dy)
+    refw = torch.nn.grad.conv2d_weight(nchw(x3), (64, 3, 3, 3), nchw(dy), padding=1)
+    check(f"conv1 wgrad B{batch}", dw.permute(0, 3, 1, 2), refw, rtol=2e-3, atol_scale=2e-3)
+    check(f"conv1 bias grad B{batch}", db, dy.float().sum(dim=(0, 1, 2)), rtol=2e-3,
+          atol_scale=2e-3)
+
+
+@pytest.mark.parametrize("c,hw", [(64, 32), (128, 16), (512, 2)])
+def test_maxpool(c, hw):
+    n = native()
+    x = rand_bf16(8, hw, hw, c, seed=14).relu()       # post-ReLU: plenty of ties at zero
+    y = n.maxpool2x2_fwd(x)
+    xr = nchw(x).requires_grad_(True)
+    ref = F.max_pool2d(xr, 2, 2)
+    check("maxpool fwd", nchw(y), ref.detach(), rtol=0, atol_scale=0)
+    dy = rand_bf16(8, hw // 2, hw // 2, c, seed=15)
+    ref.backward(nchw(dy))
+    dx = n.maxpool2x2_bwd(x, dy, relu_mask=False)
+    check("maxpool bwd", nchw(dx), xr.grad, rtol=0, atol_scale=0)
+    dxm = n.maxpool2x2_bwd(x, dy, relu_mask=True)
+    check("maxpool bwd + relu mask", nchw(dxm), xr.grad * (nchw(x) > 0), rtol=0, atol_scale=0)
+
+
+@pytest.mark.parametrize("c,rows_shape", [(64, (4, 32, 32)), (256, (16, 8, 8)), (512, (64, 2, 2))])
+def test_bn_relu(c, rows_shape):
+    n = native()
+    x = rand_bf16(*rows_shape, c, scale=2.0, seed=16) + 0.5
+    x = x.to(torch.bfloat16)
+    gamma = torch.rand(c, device=DEV) + 0.5
+    beta = torch.randn(c, device=DEV) * 0.2
+    rm = torch.zeros(c, device=DEV)
+    rv = torch.ones(c, device=DEV)
+    xr = nchw(x).requires_grad_(True)
+    g_ref = gamma.clone().requires_grad_(True)
+    b_ref = beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.relu(F.batch_norm(xr, rm_ref, rv_ref, g_ref, b_ref, True, 0.1, 1e-5))
+    y, mean, rstd = n.bn_relu_fwd_train(x, gamma, beta, rm, rv)
+    check("bn fwd", nchw(y), ref.detach())
+    check("bn running_mean", rm, rm_ref, rtol=1e-4, atol_scale=1e-4)
+    check("bn running_var", rv, rv_ref, rtol=1e-3, atol_scale=1e-3)
+    dy = rand_bf16(*rows_shape, c, seed=17)
+    ref.backward(nchw(dy))
+    dx, dgamma, dbeta = n.bn_relu_bwd(x, dy, gamma, beta, mean, rstd)
+    check("bn dgamma", dgamma, g_ref.grad, rtol=5e-3, atol_scale=5e-3)
+    check("bn dbeta", dbeta, b_ref.grad, rtol=5e-3, atol_scale=5e-3)
+    check("bn dx", nchw(dx), xr.grad, rtol=2e-2, atol_scale=2e-2)
+    ye = n.bn_relu_fwd_eval(x, gamma, beta, rm, rv)
+    refe = F.relu(F.batch_norm(nchw(x), rm, rv, gamma, beta, False, 0.1, 1e-5))
+    check("bn eval", nchw(ye), refe)
+
+
+@pytest.mark.parametrize("batch", [3, 256])
+def test_linear_and_softmax_xent(batch):
+    n = native()
+    x = rand_bf16(batch, 512, seed=18)
+    w = torch.randn(10, 512, device=DEV) * 0.05
+    b = torch.randn(10, device=DEV) * 0.1
+    t = torch.randint(0, 10, (batch,), device=DEV)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    xr = x.float().requires_grad_(True)
+    logits_ref = F.linear(xr, wr, br)
+    loss_ref = F.cross_entropy(logits_ref, t)
+    loss_ref.backward()
+    logits = n.linear_fwd(x, w, b)
+    check("linear fwd", logits, logits_ref.detach(), rtol=1e-4, atol_scale=1e-4)
+    loss, dl, correct = n.softmax_xent(logits, t)
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
+    assert int(correct) == int((logits_ref.argmax(1) == t).sum())
+    dx, dw, db = n.linear_bwd(x, w, dl)
+    check("linear dw", dw, wr.grad, rtol=1e-3, atol_scale=1e-3)
+    check("linear db", db, br.grad, rtol=1e-3, atol_scale=1e-3)
+    check("linear dx", dx, xr.grad)
+
+
+def test_fused_sgd_matches_torch():
+    n = native()
+    torch.manual_seed(0)
+    size = 4 * 25013
+    p = torch.randn(size, device=DEV)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref], lr=0.1, momentum=0.9, weight_decay=1e-4)
+    m = torch.zeros_like(p)
+    shadow = torch.empty(size, dtype=torch.bfloat16, device=DEV)
+    for step in range(4):
+        g = torch.randn(size, device=DEV)
+        ref.grad = g.clone()
+        opt.step()
+        n.sgd_momentum_(p, g, m, 0.1, 0.9, 1e-4, shadow=shadow)
+        assert torch.allclose(p, ref.detach(), rtol=1e-6, atol=1e-6), f"step {step}"
+    assert torch.equal(shadow, p.to(torch.bfloat16))
+    # grad_scale folds the 1/world_size of a mean reduction into the update
+    p2, m2 = p.clone(), torch.zeros_like(p)
+    g = torch.randn(size, device=DEV)
+    n.sgd_momentum_(p2, g * 4, m2, 0.1, 0.9, 0.0, grad_scale=0.25)
+    assert torch.allclose(p2, p - 0.1 * g, rtol=1e-6, atol=1e-6)
+
+
+def test_column_sum_and_slab_sum():
+    n = native()
+    x = rand_bf16(37, 8, 8, 128, seed=19)
+    check("column_sum", n.column_sum(x), x.float().sum(dim=(0, 1, 2)), rtol=1e-4, atol_scale=1e-4)
+    slabs = torch.randn(5, 4 * 1001, device=DEV)
+    ref = slabs.sum(0)
+    n.sum_slabs_(slabs)
+    assert torch.allclose(slabs[0], ref, rtol=1e-6, atol=1e-5)
+
+
+def test_augment_kernel_matches_reference_transform():
+    from distributed_machine_learning_amd.data import synthetic_cifar
+    from distributed_machine_learning_amd.data.transforms import (_augment_reference,
+                                                                   draw_augmentation)
+    n = native()
+    ds = synthetic_cifar(16, 3).to(DEV)
+    aug = draw_augmentation(torch.arange(16, device=DEV), 7)
+    out = n.augment_normalize(ds.images, aug)
+    ref = _augment_reference(ds.images, aug).permute(0, 2, 3, 1)
+    assert torch.allclose(out[..., :3].float(), ref, rtol=1e-2, atol=1e-2)
+    assert float(out[..., 3].abs().max()) == 0.0
+    plain = n.augment_normalize(ds.images, None)
+    assert torch.allclose(plain[..., :3].float(),
+                          _augment_reference(ds.images, None).permute(0, 2, 3, 1),
+                          rtol=1e-2, atol=1e-2)
+    x = torch.randn(4, 3, 32, 32, device=DEV)
+    assert torch.equal(n.nchw_to_nhwc4(x)[..., :3], x.permute(0, 2, 3, 1).to(torch.bfloat16))

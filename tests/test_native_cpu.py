@@ -1,0 +1,80 @@
+"""Host-side parts of the native runtime that need no GPU: the TCP store, the C++ bucket
+planner (must agree with the Python one) and the engine's layout planning."""
+import threading
+
+import pytest
+import torch
+
+from distributed_machine_learning_amd.ops import native
+from distributed_machine_learning_amd.parallel.flat import plan_buckets
+
+pytestmark = pytest.mark.skipif(not native.available(), reason="native extension not built")
+
+
+def test_tcp_store_set_get_add_barrier():
+    C = native.lib()
+    server = C.TcpStore("127.0.0.1", 0, True, 3, 20.0)
+    port = server.port
+    results = {}
+
+    def worker(rank):
+        st = C.TcpStore("127.0.0.1", port, False, 3, 20.0)
+        results[rank] = st.get("uid")          # blocks until rank 0 publishes
+        st.add("counter", rank)
+        st.barrier("done")
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in (1, 2)]
+    for t in threads:
+        t.start()
+    server.set("uid", b"\x00\x01binary\xff" * 8)
+    server.barrier("done")
+    for t in threads:
+        t.join(20)
+    assert results[1] == results[2] == b"\x00\x01binary\xff" * 8
+    assert server.add("counter", 0) == 3
+
+
+def test_tcp_store_get_times_out_cleanly():
+    C = native.lib()
+    server = C.TcpStore("127.0.0.1", 0, True, 1, 0.5)
+    with pytest.raises(RuntimeError, match="timed out"):
+        server.get("never-set")
+
+
+def test_tcp_store_connect_timeout():
+    C = native.lib()
+    with pytest.raises(RuntimeError, match="timed out"):
+        C.TcpStore("127.0.0.1", 1, False, 2, 0.3)
+
+
+def test_cpp_bucket_plan_matches_python():
+    C = native.lib()
+    sizes = [4 * s for s in (1728, 64, 73728, 128, 294912, 256, 589824, 256, 1179648, 512,
+                             2359296, 512, 2359296, 512, 2359296, 512, 5120, 10)]
+    for cap_mb in (1, 5, 25, 100):
+        assert [tuple(b) for b in C.plan_buckets(sizes, cap_mb << 20, 1 << 20)] == \
+            plan_buckets(sizes, cap_mb << 20)
+
+
+@pytest.mark.parametrize("bn", [False, True])
+def test_engine_layout(bn):
+    from distributed_machine_learning_amd.models.checkpoint import expected_shapes
+    from distributed_machine_learning_amd.models.vgg import VGG_WIDTHS, parameter_keys
+    C = native.lib()
+    widths = [-1 if w == "M" else w for w in VGG_WIDTHS["VGG11"]]
+    e = C.VggEngine(widths, 256, bn, 10)
+    slots = e.param_slots
+    assert [s.name for s in slots] == parameter_keys("VGG11", bn)
+    shapes = expected_shapes("VGG11", bn)
+    for s in slots:
+        want = shapes[s.name]
+        if len(want) == 4:
+            want = (want[0], 3, 3, want[1])
+        assert tuple(s.shape) == tuple(want)
+        assert s.offset % 64 == 0
+    assert sum(s.numel for s in slots) == (9_231_114 if bn else 9_225_610)
+    assert e.param_elems % 4 == 0
+    assert [s.name for s in e.buffer_slots][:2] == (["layers.1.running_mean",
+                                                    "layers.1.running_var"] if bn else [])
+    with pytest.raises(ValueError):
+        C.VggEngine([64, 100], 8, False, 10)
