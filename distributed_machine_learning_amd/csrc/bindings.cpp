@@ -38,19 +38,25 @@ PYBIND11_MODULE(_C, m) {
     // ------------------------------------------------------------------ kernels
     m.def("conv3x3_igemm", [](uintptr_t x, uintptr_t w, uintptr_t y, uintptr_t bias, uintptr_t mask,
                               uintptr_t ws, size_t ws_elems, int batch, int hw, int cin, int cout,
-                              int epi, uintptr_t stream) {
+                              int epi, uintptr_t stream, int bm, int bn, int splits) {
+        const int force[3] = {bm, bn, splits};
         conv3x3_igemm(ptr<const bf16_raw>(x), ptr<const bf16_raw>(w), ptr<bf16_raw>(y),
                       ptr<const float>(bias), ptr<const bf16_raw>(mask), ptr<float>(ws), ws_elems,
-                      shape(batch, hw, cin, cout), (ConvEpilogue)epi, st(stream));
-    });
+                      shape(batch, hw, cin, cout), (ConvEpilogue)epi, st(stream),
+                      bm > 0 ? force : nullptr);
+    }, py::arg("x"), py::arg("w"), py::arg("y"), py::arg("bias"), py::arg("mask"), py::arg("ws"),
+       py::arg("ws_elems"), py::arg("batch"), py::arg("hw"), py::arg("cin"), py::arg("cout"),
+       py::arg("epi"), py::arg("stream"), py::arg("bm") = 0, py::arg("bn") = 0,
+       py::arg("splits") = 0);
     m.def("conv3x3_igemm_workspace_elems", [](int batch, int hw, int cin, int cout) {
         return conv3x3_igemm_workspace_elems(shape(batch, hw, cin, cout));
     });
     m.def("conv3x3_wgrad", [](uintptr_t x, uintptr_t dy, uintptr_t dw, int batch, int hw, int cin,
-                              int cout, uintptr_t stream) {
+                              int cout, uintptr_t stream, int splits) {
         conv3x3_wgrad(ptr<const bf16_raw>(x), ptr<const bf16_raw>(dy), ptr<float>(dw),
-                      shape(batch, hw, cin, cout), st(stream));
-    });
+                      shape(batch, hw, cin, cout), st(stream), splits);
+    }, py::arg("x"), py::arg("dy"), py::arg("dw"), py::arg("batch"), py::arg("hw"),
+       py::arg("cin"), py::arg("cout"), py::arg("stream"), py::arg("splits") = 0);
     m.def("conv1_fprop", [](uintptr_t x, uintptr_t w1, uintptr_t bias, uintptr_t y, int batch,
                             bool relu, uintptr_t stream) {
         conv1_fprop(ptr<const bf16_raw>(x), ptr<const bf16_raw>(w1), ptr<const float>(bias),

@@ -187,10 +187,30 @@ void VggEngine::refresh_weights(hipStream_t stream) {
     // load_state_dict); during training the optimizer kernel keeps the shadow current.
     cast_f32_to_bf16(params_, arena_ + shadow_off_, param_elems_, stream);
     repack_conv1_weights(params_ + convs_[0].w_off, arena_ + w1_off_, stream);
+    repack_all(stream);
+}
+
+std::vector<std::vector<long long>> VggEngine::layer_table() const {
+    std::vector<std::vector<long long>> out;
+    for (const Conv& c : convs_)
+        out.push_back({c.cin, c.cout, c.hw, c.pool_after ? 1 : 0, (long long)c.pre_off,
+                       (long long)c.out_off, (long long)c.pool_off});
+    return out;
+}
+
+void VggEngine::repack_all(hipStream_t stream) {
+    // backward-data weight layout for every conv after the first, 16 layers per launch
+    RepackJobs jobs;
     for (size_t i = 1; i < convs_.size(); ++i) {
         const Conv& c = convs_[i];
-        repack_dgrad_weights(arena_ + shadow_off_ + c.w_off, arena_ + c.wd_off, c.cout, c.cin,
-                             stream);
+        jobs.cout[jobs.n] = c.cout;
+        jobs.cin[jobs.n] = c.cin;
+        jobs.src_off[jobs.n] = shadow_off_ + c.w_off;
+        jobs.dst_off[jobs.n] = c.wd_off;
+        if (++jobs.n == RepackJobs::kMax || i + 1 == convs_.size()) {
+            repack_dgrad_weights_batch(arena_, arena_, jobs, stream);
+            jobs.n = 0;
+        }
     }
 }
 
@@ -295,11 +315,7 @@ void VggEngine::optimizer_step(float lr, float momentum, float weight_decay, flo
     sgd_momentum(params_, grads_, mom_, arena_ + shadow_off_, param_elems_, lr, momentum,
                  weight_decay, grad_scale, false, stream);
     repack_conv1_weights(params_ + convs_[0].w_off, arena_ + w1_off_, stream);
-    for (size_t i = 1; i < convs_.size(); ++i) {
-        const Conv& c = convs_[i];
-        repack_dgrad_weights(arena_ + shadow_off_ + c.w_off, arena_ + c.wd_off, c.cout, c.cin,
-                             stream);
-    }
+    repack_all(stream);
 }
 
 void VggEngine::eval_step(const uint16_t* x, const int64_t* target, int batch, hipStream_t stream) {
@@ -354,6 +370,7 @@ void bind_engine(py::module_& m) {
         .def_property_readonly("param_slots", &VggEngine::param_slots)
         .def_property_readonly("buffer_slots", &VggEngine::buffer_slots)
         .def_property_readonly("num_conv", &VggEngine::num_conv)
+        .def_property_readonly("layer_table", &VggEngine::layer_table)
         .def_property("bn_steps", &VggEngine::bn_steps, &VggEngine::set_bn_steps)
         .def("bind", [](VggEngine& e, uintptr_t p, uintptr_t g, uintptr_t mo, uintptr_t bn,
                         uintptr_t arena, uintptr_t ws) {

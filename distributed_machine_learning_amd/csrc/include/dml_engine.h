@@ -84,6 +84,8 @@ class VggEngine {
     long long bn_steps() const { return bn_steps_; }
     void set_bn_steps(long long v) { bn_steps_ = v; }
     int num_conv() const { return (int)convs_.size(); }
+    // per conv layer: {cin, cout, hw, pool_after, pre_off, out_off, pool_off} (arena elements)
+    std::vector<std::vector<long long>> layer_table() const;
     ~VggEngine();
 
   private:
@@ -98,6 +100,7 @@ class VggEngine {
     };
     void backward(const uint16_t* x_nhwc4, const int64_t* target, int batch, hipStream_t stream);
     void fire_buckets(int layer, hipStream_t stream);
+    void repack_all(hipStream_t stream);
 
     std::vector<Conv> convs_;
     int max_batch_, num_classes_, fc_in_;

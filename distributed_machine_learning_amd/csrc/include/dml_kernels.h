@@ -41,7 +41,8 @@ struct ConvShape {
 // when the launcher decides to split the reduction over taps.
 void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
                    const bf16_raw* mask, float* workspace, size_t workspace_elems,
-                   ConvShape s, ConvEpilogue epi, hipStream_t stream);
+                   ConvShape s, ConvEpilogue epi, hipStream_t stream,
+                   const int* force_plan = nullptr /* {BM, BN, splits} for tuning */);
 size_t conv3x3_igemm_workspace_elems(ConvShape s);
 
 // First layer: x is [B,32,32,4] bf16 (3 channels + zero pad), w1 is [64][64] bf16 with
@@ -56,10 +57,20 @@ void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, in
 // dw[cout][9][cin] (+)= sum_p dy[p][cout] * x[p (+) tap][cin]   (fp32).  With more than one
 // split the kernel accumulates with atomics and `dw` must be zeroed by the caller.
 void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
-                   hipStream_t stream);
+                   hipStream_t stream, int force_splits = 0 /* tuning */);
 
 // wd[cin][8 - tap][cout] = wf[cout][tap][cin]   (bf16 -> bf16)
 void repack_dgrad_weights(const bf16_raw* wf, bf16_raw* wd, int cout, int cin, hipStream_t stream);
+// the same for up to 16 layers in one launch; offsets are elements from the two bases
+struct RepackJobs {
+    static constexpr int kMax = 16;
+    int n = 0;
+    int cout[kMax], cin[kMax];
+    size_t src_off[kMax], dst_off[kMax];
+    int tile_start[kMax + 1];     // filled by the launcher
+};
+void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, RepackJobs jobs,
+                                hipStream_t stream);
 // w1[64][64] bf16 (k = tap*4 + c) from master fp32 [64][9][3]
 void repack_conv1_weights(const float* w, bf16_raw* w1, hipStream_t stream);
 
@@ -95,7 +106,7 @@ void bn_relu_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const floa
 // logits[b][n] = sum_k x[b][k] * w[n][k] + bias[n]      (x bf16, w/bias/logits fp32, n <= 16)
 void linear_fwd(const bf16_raw* x, const float* w, const float* bias, float* logits, int batch,
                 int in_features, int out_features, hipStream_t stream);
-// dw (+)= dlogits^T x, db (+)= sum dlogits, dx = dlogits w  (dx bf16).  accumulate=false overwrites.
+// dw += dlogits^T x, db += sum dlogits (fp32 atomics: zero them first), dx = dlogits w (bf16).
 void linear_bwd(const bf16_raw* x, const float* w, const float* dlogits, float* dw, float* db,
                 bf16_raw* dx, int batch, int in_features, int out_features, hipStream_t stream);
 // Mean cross-entropy over the batch: loss_sum[0] += sum_b loss_b / batch,

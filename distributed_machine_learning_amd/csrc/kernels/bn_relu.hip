@@ -24,11 +24,12 @@ constexpr int kMaxBlocks = 1024;
 
 struct RowSplit { int blocks, rows_per_block; };
 
-RowSplit split_rows(int rows) {
-    int blocks = (rows + 127) / 128;
-    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
-    if (blocks < 1) blocks = 1;
-    const int rpb = (rows + blocks - 1) / blocks;
+// Enough blocks to fill the chip, but at least 4 rows per row lane (256 / (c/8) lanes per
+// block) so the LDS reduction and the atomics stay a small fraction of the work.
+RowSplit split_rows(int rows, int c) {
+    const int lanes = 256 / (c / 8);
+    int rpb = (rows + kMaxBlocks - 1) / kMaxBlocks;
+    if (rpb < 4 * lanes) rpb = 4 * lanes;
     return {(rows + rpb - 1) / rpb, rpb};
 }
 
@@ -48,7 +49,12 @@ __device__ __forceinline__ void reduce_columns2(F&& row_values, float* ws, int r
     float a[8], b[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = b[i] = 0.f;
-    for (int r = r0 + rl; r < r1; r += lanes) row_values(r, cg, a, b);
+    int r = r0 + rl;
+    for (; r + lanes < r1; r += 2 * lanes) {       // two rows in flight per thread
+        row_values(r, cg, a, b);
+        row_values(r + lanes, cg, a, b);
+    }
+    for (; r < r1; r += lanes) row_values(r, cg, a, b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         red[threadIdx.x * 8 + i] = a[i];
@@ -125,7 +131,7 @@ void bn_relu_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const
                        float eps, hipStream_t stream) {
     check(rows, c, "bn_relu_fwd_train");
     (void)hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * c, stream);
-    const RowSplit rs = split_rows(rows);
+    const RowSplit rs = split_rows(rows, c);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(rs.blocks), dim3(256), 0, stream, x, stats_ws, rows,
                        c, rs.rows_per_block);
     const size_t total8 = (size_t)rows * (c / 8);
@@ -231,7 +237,7 @@ void bn_relu_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const floa
                  hipStream_t stream) {
     check(rows, c, "bn_relu_bwd");
     (void)hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * c, stream);
-    const RowSplit rs = split_rows(rows);
+    const RowSplit rs = split_rows(rows, c);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rs.blocks), dim3(256), 0, stream, x, dy, gamma,
                        beta, save_mean, save_rstd, stats_ws, rows, c, rs.rows_per_block);
     const size_t total8 = (size_t)rows * (c / 8);

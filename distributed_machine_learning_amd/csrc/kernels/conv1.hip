@@ -51,14 +51,24 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
     const bool row_ok = pix < M;
     const int w_ = pix & 31, h_ = (pix >> 5) & 31;
     const int sw_row = (tid >> 1) & 7;
+    // nine 8-byte tap loads through a raw buffer descriptor: out-of-image taps get an
+    // out-of-range offset and come back as zeros, so all nine are in flight together
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)M * 8u, 0x00020000);
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    u32x2 taps[10];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dh = t / 3 - 1, dw = t % 3 - 1;
+        const bool ok = row_ok && (unsigned)(h_ + dh) < 32u && (unsigned)(w_ + dw) < 32u;
+        taps[t] = __builtin_amdgcn_raw_buffer_load_b64(
+            xr, ok ? (pix + dh * 32 + dw) * 8 : (int)0x80000000, 0, 0);
+    }
+    taps[9] = u32x2{0u, 0u};
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < 5) {
-            const uint2 a = load_tap(x, pix, h_, w_, 2 * c, row_ok);
-            const uint2 b = load_tap(x, pix, h_, w_, 2 * c + 1, row_ok);
-            v = make_uint4(a.x, a.y, b.x, b.y);
-        }
+        if (c < 5) v = make_uint4(taps[2 * c][0], taps[2 * c][1], taps[2 * c + 1][0], taps[2 * c + 1][1]);
         *(uint4*)(sA + tid * 128 + ((c ^ sw_row) << 4)) = v;
     }
 #pragma unroll
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
 void conv1_fprop(const bf16_raw* x, const bf16_raw* w1, const float* bias, bf16_raw* y, int batch,
                  bool relu, hipStream_t stream) {
     if (batch <= 0) return;
-    if ((long long)batch * 1024 * 64 >= (1LL << 31))
+    if ((long long)batch * 1024 * 128 >= (1LL << 31))
         throw std::invalid_argument("conv1_fprop: batch too large");
     const int M = batch * 1024;
     hipLaunchKernelGGL(conv1_fprop_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, x, w1, bias,
@@ -123,19 +133,32 @@ void conv1_fprop(const bf16_raw* x, const bf16_raw* w1, const float* bias, bf16_
 
 // ------------------------------------------------------------------ backward-weight
 // D[co][k] = sum_p dy[p][co] * col[p][k] over this block's pixel range; 4 waves = the four
-// 32x32 tiles of the 64x64 result.  Row stride 192 B keeps the transposing reads
-// conflict-free.  Result is added to dw[64][9][3] / db[64] with fp32 atomics.
+// 32x32 tiles of the 64x64 result.  The kernel is bound by streaming dy (the largest
+// gradient tensor of the network), so it is organised for bytes in flight: 128-pixel steps,
+// all loads of step s+1 issued (raw buffer loads; out-of-image taps and past-the-end rows
+// return zeros from the range check, no branches) before the MFMAs of step s, one LDS stage.
+// Row stride 192 B keeps the transposing reads conflict-free.  Results are added to
+// dw[64][9][3] / db[64] with fp32 atomics.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4c1;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2c1;
+
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __restrict__ x,
                                                           const uint16_t* __restrict__ dy,
                                                           float* __restrict__ dw,
                                                           float* __restrict__ db, int M,
                                                           int steps_per_block) {
     constexpr int S = 192;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * S];
-    char* sD = smem;               // dy tile  [64 px][64 co]
-    char* sC = smem + 64 * S;      // im2col   [64 px][64 k]
+    constexpr int PX = 128;                      // pixels per step
+    constexpr int kOOB = (int)0x80000000;
+    __shared__ __attribute__((aligned(16))) char smem[2 * PX * S];
+    char* sD = smem;               // dy tile  [128 px][64 co]
+    char* sC = smem + PX * S;      // im2col   [128 px][64 k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tco = wave & 1, tk = wave >> 1;
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)M * 8u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (unsigned)M * 128u, 0x00020000);
 
     f32x16 acc;
 #pragma unroll
@@ -146,43 +169,62 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
     const int a_off = frag_row * S + (tco * 32 + frag_col) * 2;
     const int b_off = frag_row * S + (tk * 32 + frag_col) * 2;
 
-    const int total_steps = (M + 63) / 64;
+    const int total_steps = (M + PX - 1) / PX;
     const int s0 = blockIdx.x * steps_per_block;
     const int s1 = min(total_steps, s0 + steps_per_block);
-    const int crow = tid >> 2, cq = tid & 3;      // im2col staging: row, quarter
-    for (int s = s0; s < s1; ++s) {
-        const int pbase = s * 64;
-        // dy tile: 512 chunks, two per thread
+    if (s0 >= s1) return;
+
+    // im2col staging: thread = (pixel row, half); half 0 owns taps 0..4, half 1 taps 5..8 and
+    // the constant column k = 36.  Chunks 5..7 of every row (k >= 40) stay zero.
+    const int crow = tid >> 1, chalf = tid & 1;
+    if (chalf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int c = 5; c < 8; ++c) *(uint4*)(sC + crow * S + c * 16) = make_uint4(0, 0, 0, 0);
+    }
+    u32x4c1 rd[4];
+    u32x2c1 rt[5];
+    auto load_step = [&](int s) {
+        const int pbase = s * PX;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             const int chunk = tid + 256 * i;
-            const int r = chunk >> 3, c = chunk & 7;
-            const int pix = pbase + r;
-            const uint4 v = pix < M ? *(const uint4*)(dy + (size_t)pix * 64 + c * 8)
-                                    : make_uint4(0, 0, 0, 0);
-            *(uint4*)(sD + r * S + c * 16) = v;
+            const int pix = pbase + (chunk >> 3);
+            rd[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                dr, pix < M ? pix * 128 + (chunk & 7) * 16 : kOOB, 0, 0);
         }
-        // im2col tile: thread (row, quarter) writes chunks 2*cq and 2*cq + 1
-        {
-            const int pix = pbase + crow;
-            const bool ok = pix < M;
-            const int w_ = pix & 31, h_ = (pix >> 5) & 31;
+        const int pix = pbase + crow;
+        const int w_ = pix & 31, h_ = (pix >> 5) & 31;
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const int c = 2 * cq + cc;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (c < 5) {
-                    const uint2 a = load_tap(x, pix, h_, w_, 2 * c, ok);
-                    uint2 b = load_tap(x, pix, h_, w_, 2 * c + 1, ok);
-                    if (c == 4 && ok) b.x = 0x3f80u;      // k = 36 -> bf16 1.0 (bias column)
-                    v = make_uint4(a.x, a.y, b.x, b.y);
-                }
-                *(uint4*)(sC + crow * S + c * 16) = v;
-            }
+        for (int j = 0; j < 5; ++j) {
+            const int tap = chalf * 5 + j;
+            const int dh = tap / 3 - 1, dw_ = tap % 3 - 1;
+            const bool ok = pix < M && tap < 9 && (unsigned)(h_ + dh) < 32u &&
+                            (unsigned)(w_ + dw_) < 32u;
+            rt[j] = __builtin_amdgcn_raw_buffer_load_b64(xr, ok ? (pix + dh * 32 + dw_) * 8 : kOOB,
+                                                         0, 0);
         }
-        __syncthreads();
+        if (chalf && pix < M) rt[4][0] = 0x3f80u;     // tap slot 9 = k 36: bf16 1.0 (bias column)
+    };
+    auto store_step = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int i = 0; i < 4; ++i) {
+            const int chunk = tid + 256 * i;
+            *(u32x4c1*)(sD + (chunk >> 3) * S + (chunk & 7) * 16) = rd[i];
+        }
+        // half 0: k 0..19 (taps 0..4), half 1: k 20..39 (taps 5..8 + bias column): 40 bytes each
+        char* dst = sC + crow * S + chalf * 40;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) *(u32x2c1*)(dst + j * 8) = rt[j];
+    };
+
+    load_step(s0);
+    store_step();
+    __syncthreads();
+    for (int s = s0; s < s1; ++s) {
+        const bool more = s + 1 < s1;
+        if (more) load_step(s + 1);
+#pragma unroll
+        for (int ks = 0; ks < PX / 16; ++ks) {
             const char* pa = sD + a_off + ks * 16 * S;
             const char* pb = sC + b_off + ks * 16 * S;
             const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_c1*)pa);
@@ -196,8 +238,11 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
                                                           0);
         }
         __syncthreads();
+        if (more) {
+            store_step();
+            __syncthreads();
+        }
     }
-    if (s0 >= s1) return;
     // D[co][k]: lane -> k = tk*32 + (l & 31); register r -> co
     const int k = tk * 32 + (lane & 31), lh = lane >> 5;
     const int tap = k >> 2, c = k & 3;
@@ -212,8 +257,10 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
 void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, int batch,
                  hipStream_t stream) {
     if (batch <= 0) return;
+    if ((long long)batch * 1024 * 128 >= (1LL << 31))
+        throw std::invalid_argument("conv1_wgrad: batch too large");
     const int M = batch * 1024;
-    const int total_steps = (M + 63) / 64;
+    const int total_steps = (M + 127) / 128;
     int blocks = total_steps < 512 ? total_steps : 512;
     const int spb = (total_steps + blocks - 1) / blocks;
     blocks = (total_steps + spb - 1) / spb;

@@ -37,7 +37,7 @@
 
 namespace dml {
 
-namespace {
+namespace igemm {
 
 struct IgemmArgs {
     const uint16_t* x;
@@ -51,7 +51,12 @@ struct IgemmArgs {
     int log_chunks;       // log2(C / 64)
     int tiles_n;
     int taps_per_split;
+    unsigned x_bytes;     // extents for the buffer descriptors (out-of-range loads return 0)
+    unsigned w_bytes;
 };
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr int kOutOfRange = (int)0x80000000;   // voffset beyond any tensor: hardware returns zeros
 
 __device__ __forceinline__ float4 epilogue4(f32x4 a, int epi, const float* bias, int n,
                                             const uint16_t* mask, size_t off) {
@@ -74,20 +79,30 @@ __device__ __forceinline__ float4 epilogue4(f32x4 a, int epi, const float* bias,
     return v;
 }
 
-template <int BM, int BN, int WAVES_M, int EPI, bool SPLIT>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <int BM, int BN, int WAVES_M, int EPI, bool SPLIT, int NS>
 __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;     // 1 KiB wave-loads per step and wave
+    constexpr int LPS = A_IT + B_IT;                  // loads per step per wave
+    constexpr int D = NS - 1;                         // prefetch distance in K steps
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16");
+    static_assert(NS >= 2 && NS <= 4, "2..4 LDS stages");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
 
     const int tile_n = blockIdx.x % p.tiles_n;
@@ -95,55 +110,66 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tap_begin = SPLIT ? blockIdx.y * p.taps_per_split : 0;
     const int tap_end = SPLIT ? min(9, tap_begin + p.taps_per_split) : 9;
+    const int ntaps = tap_end - tap_begin;
 
     const int C = p.C, hw = p.hw;
-    const int chunks_mask = (1 << p.log_chunks) - 1;
-    const int steps = (tap_end - tap_begin) << p.log_chunks;
+    const int steps = ntaps << p.log_chunks;
 
-    // ---- staging ownership: thread -> (row r0 + 32 i, 16-byte chunk c16) of both tiles
-    const int c16 = tid & 7;
-    const int r0 = tid >> 3;
-    int pix_off[A_IT];       // element offset of (b,h,w,0) or -1 when the row is past M
+    // ---- staging.  Wave w streams rows [w*BM/4, (w+1)*BM/4) of the pixel tile and the same
+    // share of the weight tile straight into LDS (buffer_load ... lds: 16 B per lane, 8 rows =
+    // 1 KiB per wave instruction, no VGPR round trip).  The LDS image of such a load is
+    // lane-linear, so the bank swizzle is applied on the SOURCE side: lane (row, slot)
+    // fetches the 16-byte chunk slot ^ ((row >> 1) & 7) of its row.  Halo taps and rows past
+    // M get an out-of-range offset, for which the buffer range check writes zeros.
+    const int lrow = lane >> 3, slot = lane & 7;
+    int pix_off[A_IT];       // element offset of (b,h,w,chunk) or -1 when the row is past M
     int pix_hw[A_IT];        // (h << 16) | w
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int r = wave * (BM / 4) + i * 8 + lrow;
+        const int m = m0 + r;
         const int w_ = m & (hw - 1);
         const int h_ = (m >> p.log_hw) & (hw - 1);
         pix_hw[i] = (h_ << 16) | w_;
-        pix_off[i] = (m < p.M) ? m * C : -1;
+        pix_off[i] = (m < p.M) ? m * C + ((slot ^ ((r >> 1) & 7)) << 3) : -1;
     }
-    const uint16_t* wrow = p.w + (size_t)(n0 + r0) * 9 * C + c16 * 8;
+    int w_off[B_IT];         // byte offset of (n, tap 0, chunk) in the weight matrix
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int r = wave * (BN / 4) + i * 8 + lrow;
+        w_off[i] = ((n0 + r) * 9 * C + ((slot ^ ((r >> 1) & 7)) << 3)) * 2;
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
-    uint4 ra[A_IT], rb[B_IT];
-    auto load_step = [&](int s) {
-        const int tap = tap_begin + (s >> p.log_chunks);
-        const int cc = s & chunks_mask;
+    // K order: channel chunk outer, tap inner - nine consecutive steps re-read the same
+    // 128-byte lines of neighbouring pixels, so all but the first come from L1/L2.
+    auto issue = [&](int s) {
+        const int cc = s / ntaps;
+        const int tap = tap_begin + (s - cc * ntaps);
         const int dh = tap / 3 - 1, dw = tap % 3 - 1;
-        const int shift = (dh * hw + dw) * C + cc * 64 + c16 * 8;
+        const int shift = (dh * hw + dw) * C + cc * 64;
+        char* sA = smem + (s % NS) * STAGE_BYTES + wave * (BM / 4) * 128;
+        char* sB = smem + (s % NS) * STAGE_BYTES + BM * 128 + wave * (BN / 4) * 128;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int hh = (pix_hw[i] >> 16) + dh, ww = (pix_hw[i] & 0xffff) + dw;
             const bool ok = pix_off[i] >= 0 && (unsigned)hh < (unsigned)hw &&
                             (unsigned)ww < (unsigned)hw;
-            ra[i] = ok ? *(const uint4*)(p.x + (pix_off[i] + shift)) : make_uint4(0, 0, 0, 0);
+            const int voff = ok ? (pix_off[i] + shift) * 2 : kOutOfRange;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(sA + i * 1024), 16, voff, 0,
+                                                     0, 0);
         }
-        const uint16_t* wsrc = wrow + tap * C + cc * 64;
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[i] = *(const uint4*)(wsrc + (size_t)(32 * i) * 9 * C);
-    };
-    auto store_step = [&](int stage) {
-        char* sA = smem + stage * STAGE_BYTES;
-        char* sB = sA + BM * 128;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int r = r0 + 32 * i;
-            *(uint4*)(sA + r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4)) = ra[i];
-        }
+        const int wshift = (tap * C + cc * 64) * 2;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int r = r0 + 32 * i;
-            *(uint4*)(sB + r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4)) = rb[i];
+            // (the offset must be a named value: hipcc's host pass rejects the whole kernel
+            // template when an expression is passed in this argument position)
+            const int voff = w_off[i] + wshift;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + i * 1024), 16, voff, 0,
+                                                     0, 0);
         }
     };
 
@@ -181,17 +207,22 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
         }
     };
 
-    if (steps > 0) {
-        load_step(0);
-        store_step(0);
-        __syncthreads();
-        for (int s = 0; s < steps; ++s) {
-            const bool more = s + 1 < steps;
-            if (more) load_step(s + 1);
-            compute(s & 1);
-            if (more) store_step((s + 1) & 1);
-            __syncthreads();
-        }
+    // Pipeline: the loads of steps s+1 .. s+D-1 stay in flight across the barrier while step
+    // s is multiplied (counted vmcnt, raw s_barrier).  Iteration s: wait until this wave's
+    // loads of step s have landed, barrier (everyone's have, and everyone is done reading
+    // the stage of step s-1), refill that stage with step s+D, then the MFMAs of step s.
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < steps) issue(s);
+    for (int s = 0; s < steps; ++s) {
+        const int ahead = min(D - 1, steps - 1 - s);
+        if (ahead >= 2) wait_vmcnt<2 * LPS>();
+        else if (ahead == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + D < steps) issue(s + D);
+        compute(s % NS);
     }
 
     // ---- epilogue: D[n][m]; lane holds n = nb + 4*lq + {0..3}, m = mb + l15
@@ -216,6 +247,18 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
         }
     }
 }
+
+// Explicit instantiations of every (tile, epilogue) variant the launcher can pick.
+#define DML_IGEMM_INSTANTIATE(BM, BN, NS)                                                        \
+    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_NONE, true, NS>(IgemmArgs);     \
+    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_NONE, false, NS>(IgemmArgs);    \
+    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_BIAS, false, NS>(IgemmArgs);    \
+    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_BIAS_RELU, false, NS>(IgemmArgs); \
+    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_MASK, false, NS>(IgemmArgs);
+DML_IGEMM_INSTANTIATE(128, 128, 3)
+DML_IGEMM_INSTANTIATE(128, 64, 3)
+DML_IGEMM_INSTANTIATE(64, 64, 4)
+#undef DML_IGEMM_INSTANTIATE
 
 // Sums the per-split fp32 slabs and applies the epilogue; 4 outputs per thread.
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slab,
@@ -250,46 +293,50 @@ struct Plan {
     int bm, bn, splits;
 };
 
-// Tile / split choice: biggest tile that still gives >= ~0.8 blocks per CU; otherwise the
-// smallest tile plus a tap split (3 or 9 ways) until the grid fills the chip.
-Plan choose_plan(int M, int N) {
-    const int kCUs = 256;
+// Tile / split choice, from per-layer timings on MI355X at batch 256 (tools/bench_conv.py):
+// with the LDS-DMA pipeline a K step is latency-bound per block, so the fastest plan is the
+// one that keeps >= 2 blocks per CU resident - 128x64 once that still gives >= 512 blocks,
+// else 64x64; layers that cannot reach one block per CU even at 64x64 split the taps.
+Plan choose_plan(int M, int N, const int* force = nullptr) {
+    if (force && force[0] > 0) return {force[0], force[1], force[2] > 0 ? force[2] : 1};
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (N / bn); };
-    if (N % 128 == 0 && blocks(128, 128) >= 200) return {128, 128, 1};
-    if (blocks(128, 64) >= 200) return {128, 64, 1};
-    if (blocks(64, 64) >= 200) return {64, 64, 1};
+    if (blocks(128, 64) >= 512) return {128, 64, 1};
     const int b = blocks(64, 64);
-    if (b * 3 >= kCUs / 2) return {64, 64, 3};
+    if (b >= 256) return {64, 64, 1};
+    if (b * 3 >= 128) return {64, 64, 3};
     return {64, 64, 9};
 }
 
-template <int BM, int BN, int WAVES_M>
+template <int BM, int BN, int WAVES_M, int EPI, bool SPLIT, int NS>
+void launch_one(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
+    constexpr int lds = NS * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI, SPLIT, NS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI, SPLIT, NS>), grid, dim3(256), lds,
+                       stream, a);
+}
+
+// LDS stages per tile: 128x128 -> 3 x 32 KiB (one block per CU), 128x64 -> 3 x 24 KiB and
+// 64x64 -> 4 x 16 KiB (two blocks per CU).
+template <int BM, int BN, int WAVES_M, int NS>
 void launch_cfg(const IgemmArgs& a, int epi, int splits, hipStream_t stream) {
     const int tiles_m = (a.M + BM - 1) / BM;
-    const dim3 grid(tiles_m * a.tiles_n, splits), block(256);
-    const size_t lds = 2 * (BM + BN) * 128;
+    const dim3 grid(tiles_m * a.tiles_n, splits);
     if (splits > 1) {
-        hipLaunchKernelGGL((conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI_NONE, true>), grid, block,
-                           lds, stream, a);
+        launch_one<BM, BN, WAVES_M, EPI_NONE, true, NS>(a, grid, stream);
         return;
     }
     switch (epi) {
-        case EPI_NONE:
-            hipLaunchKernelGGL((conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI_NONE, false>), grid,
-                               block, lds, stream, a);
-            break;
-        case EPI_BIAS:
-            hipLaunchKernelGGL((conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI_BIAS, false>), grid,
-                               block, lds, stream, a);
-            break;
+        case EPI_NONE: launch_one<BM, BN, WAVES_M, EPI_NONE, false, NS>(a, grid, stream); break;
+        case EPI_BIAS: launch_one<BM, BN, WAVES_M, EPI_BIAS, false, NS>(a, grid, stream); break;
         case EPI_BIAS_RELU:
-            hipLaunchKernelGGL((conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI_BIAS_RELU, false>), grid,
-                               block, lds, stream, a);
+            launch_one<BM, BN, WAVES_M, EPI_BIAS_RELU, false, NS>(a, grid, stream);
             break;
-        default:
-            hipLaunchKernelGGL((conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI_MASK, false>), grid,
-                               block, lds, stream, a);
-            break;
+        default: launch_one<BM, BN, WAVES_M, EPI_MASK, false, NS>(a, grid, stream); break;
     }
 }
 
@@ -304,17 +351,19 @@ void check_shape(const ConvShape& s, const char* who) {
         throw std::invalid_argument(std::string(who) + ": tensor exceeds 2^31 elements");
 }
 
-}  // namespace
+}  // namespace igemm
+using namespace igemm;
 
 size_t conv3x3_igemm_workspace_elems(ConvShape s) {
     const int M = s.batch * s.hw * s.hw;
     const Plan pl = choose_plan(M, s.cout);
-    return pl.splits > 1 ? (size_t)pl.splits * M * s.cout : 0;
+    // room for the widest split so a forced plan (tuning) never outgrows the buffer
+    return pl.splits > 1 ? (size_t)9 * M * s.cout : 0;
 }
 
 void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
                    const bf16_raw* mask, float* workspace, size_t workspace_elems, ConvShape s,
-                   ConvEpilogue epi, hipStream_t stream) {
+                   ConvEpilogue epi, hipStream_t stream, const int* force_plan) {
     check_shape(s, "conv3x3_igemm");
     if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias)
         throw std::invalid_argument("conv3x3_igemm: bias epilogue without bias");
@@ -323,7 +372,12 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.mask = mask; a.slab = workspace;
     a.M = s.batch * s.hw * s.hw; a.N = s.cout; a.C = s.cin;
     a.hw = s.hw; a.log_hw = ilog2(s.hw); a.log_chunks = ilog2(s.cin / 64);
-    const Plan pl = choose_plan(a.M, a.N);
+    const Plan pl = choose_plan(a.M, a.N, force_plan);
+    if (!((pl.bm == 128 || pl.bm == 64) && (pl.bn == 128 || pl.bn == 64) && a.N % pl.bn == 0 &&
+          (pl.splits == 1 || pl.splits == 3 || pl.splits == 9)) || (pl.bm == 64 && pl.bn == 128))
+        throw std::invalid_argument("conv3x3_igemm: unsupported tile plan");
+    a.x_bytes = (unsigned)((size_t)a.M * a.C * 2);
+    a.w_bytes = (unsigned)((size_t)a.N * 9 * a.C * 2);
     a.tiles_n = a.N / pl.bn;
     a.taps_per_split = 9 / pl.splits;
     if (pl.splits > 1) {
@@ -331,9 +385,9 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
         if (!workspace || workspace_elems < need)
             throw std::invalid_argument("conv3x3_igemm: workspace too small for the tap split");
     }
-    if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 2>(a, epi, pl.splits, stream);
-    else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 2>(a, epi, pl.splits, stream);
-    else launch_cfg<64, 64, 2>(a, epi, pl.splits, stream);
+    if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 2, 3>(a, epi, pl.splits, stream);
+    else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 2, 3>(a, epi, pl.splits, stream);
+    else launch_cfg<64, 64, 2, 4>(a, epi, pl.splits, stream);
     if (pl.splits > 1) {
         const size_t total4 = (size_t)a.M * a.N / 4;
         hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256),

@@ -55,7 +55,11 @@ struct WgradArgs {
     int tiles_ci, tiles_co;
     int steps_per_split;   // K steps (64 pixels each) per blockIdx.y
     int atomic;
+    unsigned x_bytes, dy_bytes;   // extents for the buffer descriptors
 };
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4w;
+constexpr int kOutOfRangeW = (int)0x80000000;
 
 template <int BCO, int BCI>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
@@ -89,15 +93,21 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
     const int b_c = tid % B_CH, b_r = tid / B_CH;       // x staging ownership
     constexpr int A_RSTEP = 256 / A_CH, B_RSTEP = 256 / B_CH;
 
-    uint4 ra[A_IT], rb[B_IT];
+    // Both operands are fetched through raw buffer descriptors; rows past the end and taps
+    // that fall into the padding get an out-of-range offset, for which the hardware returns
+    // zeros - no branches, no selects, loads stay in flight across the MFMAs.
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dyrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    u32x4w ra[A_IT], rb[B_IT];
     auto load_step = [&](int s) {
         const int pbase = s * 64;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int pix = pbase + a_r + i * A_RSTEP;
-            ra[i] = (pix < p.M)
-                        ? *(const uint4*)(p.dy + (size_t)pix * p.Cout + co0 + a_c * 8)
-                        : make_uint4(0, 0, 0, 0);
+            const int voff = (pix < p.M) ? (pix * p.Cout + co0 + a_c * 8) * 2 : kOutOfRangeW;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(dyrsrc, voff, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -105,8 +115,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
             const int ww = (pix & (hw - 1)) + dw_;
             const int hh = ((pix >> p.log_hw) & (hw - 1)) + dh;
             const bool ok = pix < p.M && (unsigned)hh < (unsigned)hw && (unsigned)ww < (unsigned)hw;
-            rb[i] = ok ? *(const uint4*)(p.x + (size_t)(pix + dh * hw + dw_) * p.Cin + ci0 + b_c * 8)
-                       : make_uint4(0, 0, 0, 0);
+            const int voff = ok ? ((pix + dh * hw + dw_) * p.Cin + ci0 + b_c * 8) * 2 : kOutOfRangeW;
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
         }
     };
     auto store_step = [&](int stage) {
@@ -114,10 +124,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
         char* sB = sA + 64 * SA;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            *(uint4*)(sA + (a_r + i * A_RSTEP) * SA + a_c * 16) = ra[i];
+            *(u32x4w*)(sA + (a_r + i * A_RSTEP) * SA + a_c * 16) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            *(uint4*)(sB + (b_r + i * B_RSTEP) * SB + b_c * 16) = rb[i];
+            *(u32x4w*)(sB + (b_r + i * B_RSTEP) * SB + b_c * 16) = rb[i];
     };
 
     f32x16 acc[TCO][TCI];
@@ -198,7 +208,7 @@ int ilog2w(int v) {
 }
 
 template <int BCO, int BCI>
-void launch_wgrad(WgradArgs a, hipStream_t stream) {
+void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits) {
     a.tiles_co = a.Cout / BCO;
     a.tiles_ci = a.Cin / BCI;
     const int tiles = a.tiles_co * a.tiles_ci * 9;
@@ -207,6 +217,7 @@ void launch_wgrad(WgradArgs a, hipStream_t stream) {
     int splits = (288 + tiles - 1) / tiles;
     const int max_splits = total_steps >= 4 ? total_steps / 4 : 1;
     if (splits > max_splits) splits = max_splits;
+    if (force_splits > 0) splits = force_splits < total_steps ? force_splits : total_steps;
     if (splits < 1) splits = 1;
     a.steps_per_split = (total_steps + splits - 1) / splits;
     splits = (total_steps + a.steps_per_split - 1) / a.steps_per_split;
@@ -225,7 +236,7 @@ void launch_wgrad(WgradArgs a, hipStream_t stream) {
 }  // namespace
 
 void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
-                   hipStream_t stream) {
+                   hipStream_t stream, int force_splits) {
     if (s.batch <= 0 || s.hw < 1 || s.hw > 32 || (s.hw & (s.hw - 1)) || s.cin % 64 ||
         s.cout % 128 || s.cin < 64)
         throw std::invalid_argument("conv3x3_wgrad: needs hw power of two <= 32, cin % 64 == 0, "
@@ -235,17 +246,19 @@ void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s
     a.M = s.batch * s.hw * s.hw; a.Cin = s.cin; a.Cout = s.cout;
     a.hw = s.hw; a.log_hw = ilog2w(s.hw);
     a.tiles_ci = a.tiles_co = 0; a.steps_per_split = 0; a.atomic = 0;
-    if (s.cin % 128 == 0) launch_wgrad<128, 128>(a, stream);
-    else launch_wgrad<128, 64>(a, stream);
+    if ((long long)a.M * (s.cin > s.cout ? s.cin : s.cout) >= (1LL << 30))
+        throw std::invalid_argument("conv3x3_wgrad: tensor exceeds 2^31 bytes");
+    a.x_bytes = (unsigned)((size_t)a.M * s.cin * 2);
+    a.dy_bytes = (unsigned)((size_t)a.M * s.cout * 2);
+    if (s.cin % 128 == 0) launch_wgrad<128, 128>(a, stream, force_splits);
+    else launch_wgrad<128, 64>(a, stream, force_splits);
 }
 
 // ------------------------------------------------------------------ weight repacks
 // wd[ci][8 - tap][co] = wf[co][tap][ci]: a 64x64 bf16 transpose per (tap, tile) through LDS.
-__global__ __launch_bounds__(256) void repack_dgrad_kernel(const uint16_t* __restrict__ wf,
-                                                           uint16_t* __restrict__ wd, int cout,
-                                                           int cin) {
-    __shared__ uint16_t tile[64][66];
-    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, tap = blockIdx.z;
+__device__ __forceinline__ void repack_tile(const uint16_t* __restrict__ wf,
+                                            uint16_t* __restrict__ wd, int cout, int cin,
+                                            int ci0, int co0, int tap, uint16_t (*tile)[66]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -273,10 +286,49 @@ __global__ __launch_bounds__(256) void repack_dgrad_kernel(const uint16_t* __res
     }
 }
 
+__global__ __launch_bounds__(256) void repack_dgrad_kernel(const uint16_t* __restrict__ wf,
+                                                           uint16_t* __restrict__ wd, int cout,
+                                                           int cin) {
+    __shared__ uint16_t tile[64][66];
+    repack_tile(wf, wd, cout, cin, blockIdx.x * 64, blockIdx.y * 64, blockIdx.z, tile);
+}
+
 void repack_dgrad_weights(const bf16_raw* wf, bf16_raw* wd, int cout, int cin, hipStream_t stream) {
     if (cout % 64 || cin % 64) throw std::invalid_argument("repack_dgrad_weights: dims % 64 != 0");
     hipLaunchKernelGGL(repack_dgrad_kernel, dim3(cin / 64, cout / 64, 9), dim3(256), 0, stream, wf,
                        wd, cout, cin);
+}
+
+// All layers of a model in one launch: block -> (layer, ci tile, co tile, tap).
+__global__ __launch_bounds__(256) void repack_dgrad_batch_kernel(const uint16_t* __restrict__ src,
+                                                                 uint16_t* __restrict__ dst,
+                                                                 RepackJobs jobs) {
+    __shared__ uint16_t tile[64][66];
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.tile_start[j + 1]) ++j;
+    int t = blockIdx.x - jobs.tile_start[j];
+    const int cin = jobs.cin[j], cout = jobs.cout[j];
+    const int tci = cin / 64, tco = cout / 64;
+    const int ci_t = t % tci; t /= tci;
+    const int co_t = t % tco; t /= tco;
+    repack_tile(src + jobs.src_off[j], dst + jobs.dst_off[j], cout, cin, ci_t * 64, co_t * 64, t,
+                tile);
+}
+
+void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, RepackJobs jobs,
+                                hipStream_t stream) {
+    if (jobs.n <= 0) return;
+    if (jobs.n > RepackJobs::kMax) throw std::invalid_argument("repack batch: too many layers");
+    int total = 0;
+    for (int j = 0; j < jobs.n; ++j) {
+        if (jobs.cout[j] % 64 || jobs.cin[j] % 64)
+            throw std::invalid_argument("repack batch: dims % 64 != 0");
+        jobs.tile_start[j] = total;
+        total += (jobs.cin[j] / 64) * (jobs.cout[j] / 64) * 9;
+    }
+    jobs.tile_start[jobs.n] = total;
+    hipLaunchKernelGGL(repack_dgrad_batch_kernel, dim3(total), dim3(256), 0, stream, src_base,
+                       dst_base, jobs);
 }
 
 __global__ __launch_bounds__(256) void repack_conv1_kernel(const float* __restrict__ w,

@@ -150,22 +150,47 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(
     *(uint4*)(dx + (size_t)b * k + k0) = pack8(acc);
 }
 
-// dw[n][k] = sum_b dl[b][n] x[b][k]; db[n] = sum_b dl[b][n].  One thread per (n, k); the
-// batch loop reads x coalesced across k and dl as a broadcast.
+// dw[n][k] += sum_b dl[b][n] x[b][k]; db[n] += sum_b dl[b][n].  Grid = (k / 64, batch / 32):
+// a block owns 64 input features x 32 batch rows; thread = (feature, row lane), 16 output
+// accumulators in registers, row lanes combined through LDS, one atomic per (n, k) per block.
 __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ dl, float* __restrict__ dw,
     float* __restrict__ db, int batch, int k, int nout) {
-    const int kk = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = blockIdx.y;
-    if (kk >= k) return;
-    float acc = 0.f, accb = 0.f;
-    for (int b = 0; b < batch; ++b) {
-        const float d = dl[(size_t)b * nout + n];
-        acc += d * bf16_bits_to_float(x[(size_t)b * k + kk]);
-        accb += d;
+    __shared__ float red[4][64][17];
+    const int kl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int kk = blockIdx.x * 64 + kl;
+    const int b0 = blockIdx.y * 32;
+    float acc[16], accb[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) acc[n] = accb[n] = 0.f;
+    for (int b = b0 + rl; b < min(batch, b0 + 32); b += 4) {
+        const float xv = kk < k ? bf16_bits_to_float(x[(size_t)b * k + kk]) : 0.f;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const float d = n < nout ? dl[(size_t)b * nout + n] : 0.f;
+            acc[n] += d * xv;
+            accb[n] += d;
+        }
     }
-    dw[(size_t)n * k + kk] = acc;
-    if (kk == 0) db[n] = accb;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) red[rl][kl][n] = acc[n];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int n = i >> 6, kc = i & 63;
+        if (n < nout && blockIdx.x * 64 + kc < k)
+            atomicAdd(dw + (size_t)n * k + blockIdx.x * 64 + kc,
+                      red[0][kc][n] + red[1][kc][n] + red[2][kc][n] + red[3][kc][n]);
+    }
+    if (blockIdx.x == 0 && db) {
+        __syncthreads();
+        if (kl == 0)
+#pragma unroll
+            for (int n = 0; n < 16; ++n) red[rl][0][n] = accb[n];
+        __syncthreads();
+        if (threadIdx.x < nout)
+            atomicAdd(db + threadIdx.x, red[0][0][threadIdx.x] + red[1][0][threadIdx.x] +
+                                            red[2][0][threadIdx.x] + red[3][0][threadIdx.x]);
+    }
 }
 
 void linear_bwd(const bf16_raw* x, const float* w, const float* dlogits, float* dw, float* db,
@@ -178,7 +203,8 @@ void linear_bwd(const bf16_raw* x, const float* w, const float* dlogits, float* 
                            0, stream, w, dlogits, dx, batch, in_features, out_features);
     }
     if (dw) {
-        hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((in_features + 255) / 256, out_features),
+        if (out_features > 16) throw std::invalid_argument("linear_bwd: out_features > 16");
+        hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((in_features + 63) / 64, (batch + 31) / 32),
                            dim3(256), 0, stream, x, dlogits, dw, db, batch, in_features,
                            out_features);
     }

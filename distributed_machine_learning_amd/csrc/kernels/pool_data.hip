@@ -110,7 +110,22 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const uint16_t* __restr
     const int r1 = min(rows, r0 + rows_per_block);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (rl < lanes) {
-        for (int r = r0 + rl; r < r1; r += lanes) {
+        // four independent 16-byte loads in flight per thread
+        int r = r0 + rl;
+        for (; r + 3 * lanes < r1; r += 4 * lanes) {
+            uint4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                q[u] = *(const uint4*)(x + (size_t)(r + u * lanes) * c + cg * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[8];
+                unpack8(q[u], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += v[i];
+            }
+        }
+        for (; r < r1; r += lanes) {
             float v[8];
             unpack8(*(const uint4*)(x + (size_t)r * c + cg * 8), v);
 #pragma unroll
@@ -133,10 +148,12 @@ void column_sum(const bf16_raw* x, float* out, int rows, int cols, hipStream_t s
     if (cols % 8 || cols < 8 || cols > 2048 || (256 % (cols / 8)) != 0)
         throw std::invalid_argument("column_sum: cols must be 8*2^k, <= 2048");
     if (rows <= 0) return;
-    int blocks = (rows + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    const int rpb = (rows + blocks - 1) / blocks;
-    blocks = (rows + rpb - 1) / rpb;
+    // enough blocks to fill the chip, but at least 4 rows per row lane so the per-block
+    // reduction and its atomics stay a small fraction of the work
+    const int lanes = 256 / (cols / 8);
+    int rpb = (rows + 1023) / 1024;
+    if (rpb < 4 * lanes) rpb = 4 * lanes;
+    const int blocks = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(column_sum_kernel, dim3(blocks), dim3(256), 0, stream, x, out, rows, cols,
                        rpb);
 }

