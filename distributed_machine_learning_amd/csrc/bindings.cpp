@@ -63,18 +63,21 @@ PYBIND11_MODULE(_C, m) {
                     ptr<bf16_raw>(y), batch, relu, st(stream));
     });
     m.def("conv1_wgrad", [](uintptr_t x, uintptr_t dy, uintptr_t dw, uintptr_t db, int batch,
-                            uintptr_t stream) {
+                            uintptr_t ws, uintptr_t stream) {
         conv1_wgrad(ptr<const bf16_raw>(x), ptr<const bf16_raw>(dy), ptr<float>(dw), ptr<float>(db),
-                    batch, st(stream));
+                    batch, ptr<float>(ws), st(stream));
     });
+    m.def("conv1_wgrad_workspace_elems", &conv1_wgrad_workspace_elems);
+    m.def("column_reduce_workspace_elems", &bn_workspace_elems);
     m.def("repack_dgrad_weights", [](uintptr_t wf, uintptr_t wd, int cout, int cin, uintptr_t s) {
         repack_dgrad_weights(ptr<const bf16_raw>(wf), ptr<bf16_raw>(wd), cout, cin, st(s));
     });
     m.def("repack_conv1_weights", [](uintptr_t w, uintptr_t w1, uintptr_t s) {
         repack_conv1_weights(ptr<const float>(w), ptr<bf16_raw>(w1), st(s));
     });
-    m.def("column_sum", [](uintptr_t x, uintptr_t out, int rows, int cols, uintptr_t s) {
-        column_sum(ptr<const bf16_raw>(x), ptr<float>(out), rows, cols, st(s));
+    m.def("column_sum", [](uintptr_t x, uintptr_t out, int rows, int cols, uintptr_t ws,
+                           uintptr_t s) {
+        column_sum(ptr<const bf16_raw>(x), ptr<float>(out), rows, cols, ptr<float>(ws), st(s));
     });
     m.def("maxpool2x2_fwd", [](uintptr_t x, uintptr_t y, int batch, int hw, int c, uintptr_t s) {
         maxpool2x2_fwd(ptr<const bf16_raw>(x), ptr<bf16_raw>(y), batch, hw, c, st(s));

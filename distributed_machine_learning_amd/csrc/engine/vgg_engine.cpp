@@ -128,7 +128,7 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
     logits_off_ = w;  w = align_up(w + B * 16);
     dlogits_off_ = w; w = align_up(w + B * 16);
     loss_off_ = w;    w = align_up(w + 64);
-    stats_off_ = w;   w = align_up(w + 2 * 2048);
+    stats_off_ = w;   w = align_up(w + bn_workspace_elems());   // column-reduction scratch
     for (auto& c : convs_) {
         c.save_off = w;
         if (bn_) w = align_up(w + 2 * (size_t)c.cout);
@@ -142,6 +142,10 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         const size_t need_d = conv3x3_igemm_workspace_elems(d);
         slab_elems_ = need_f > slab_elems_ ? need_f : slab_elems_;
         slab_elems_ = need_d > slab_elems_ ? need_d : slab_elems_;
+    }
+    {
+        const size_t need_c1 = conv1_wgrad_workspace_elems(max_batch_);
+        slab_elems_ = need_c1 > slab_elems_ ? need_c1 : slab_elems_;
     }
     slab_off_ = w; w = align_up(w + slab_elems_);
     ws_elems_ = w;
@@ -280,12 +284,16 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
         }
         const uint16_t* g = arena_ + gbuf_off_[cur];       // dL/d(conv output), mask applied
         if (i == 0) {
-            conv1_wgrad(x, g, grads_ + c.w_off, grads_ + c.b_off, batch, stream);
+            conv1_wgrad(x, g, grads_ + c.w_off, bn_ ? nullptr : grads_ + c.b_off, batch, slab,
+                        stream);
         } else {
             const Conv& prev = convs_[i - 1];
             const uint16_t* in = arena_ + (prev.pool_after ? prev.pool_off : prev.out_off);
             ConvShape s = {batch, c.hw, c.cin, c.cout};
-            column_sum(g, grads_ + c.b_off, rows, c.cout, stream);
+            // Conv bias gradient.  Under BatchNorm it is exactly zero in exact arithmetic (the
+            // normalisation removes any per-channel offset; a framework's value there is
+            // rounding noise), so it is left at the zero the gradient memset wrote.
+            if (!bn_) column_sum(g, grads_ + c.b_off, rows, c.cout, ws_ + stats_off_, stream);
             conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream);
             // input gradient; the producer's ReLU is folded in when nothing sits in between
             ConvShape d = {batch, c.hw, c.cout, c.cin};

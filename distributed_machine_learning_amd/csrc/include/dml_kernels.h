@@ -49,10 +49,11 @@ size_t conv3x3_igemm_workspace_elems(ConvShape s);
 // k = tap*4 + c (k >= 36 zero), y = relu?(conv + bias) as [B,32,32,64] bf16.
 void conv1_fprop(const bf16_raw* x, const bf16_raw* w1, const float* bias, bf16_raw* y,
                  int batch, bool relu, hipStream_t stream);
-// dW1[64][9][3] += sum_p dy[p][co] * x[p (+) tap][c],  db[64] += sum_p dy[p][co]  (fp32 atomics,
-// outputs must be zeroed by the caller).
+// dW1[64][9][3] += sum_p dy[p][co] * x[p (+) tap][c],  db[64] += sum_p dy[p][co].
+// `ws`: conv1_wgrad_workspace_elems(batch) floats of scratch for the per-block partials.
 void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, int batch,
-                 hipStream_t stream);
+                 float* ws, hipStream_t stream);
+size_t conv1_wgrad_workspace_elems(int batch);
 
 // dw[cout][9][cin] (+)= sum_p dy[p][cout] * x[p (+) tap][cin]   (fp32).  With more than one
 // split the kernel accumulates with atomics and `dw` must be zeroed by the caller.
@@ -74,8 +75,10 @@ void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, Re
 // w1[64][64] bf16 (k = tap*4 + c) from master fp32 [64][9][3]
 void repack_conv1_weights(const float* w, bf16_raw* w1, hipStream_t stream);
 
-// out[c] += sum_m x[m][c]   (fp32 atomics; out zeroed by the caller)
-void column_sum(const bf16_raw* x, float* out, int rows, int cols, hipStream_t stream);
+// out[c] += sum_m x[m][c].  `ws`: column_sum_workspace_elems() floats, zero before first use
+// (it holds a ticket counter that every launch leaves at zero again).
+void column_sum(const bf16_raw* x, float* out, int rows, int cols, float* ws, hipStream_t stream);
+size_t column_sum_workspace_elems();
 
 // ---------------------------------------------------------------- maxpool 2x2 stride 2
 void maxpool2x2_fwd(const bf16_raw* x, bf16_raw* y, int batch, int hw, int c, hipStream_t stream);
@@ -87,7 +90,7 @@ void maxpool2x2_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, int bat
 // ---------------------------------------------------------------- BatchNorm + ReLU (NHWC)
 // Training forward: batch statistics over rows, y = relu(gamma * (x - mean) * rstd + beta),
 // running stats updated with `momentum` (unbiased variance), save_mean/save_rstd kept for
-// backward.  `stats_ws` is 2*c floats of scratch.
+// backward.  `stats_ws` is bn_workspace_elems() floats, zero before first use.
 void bn_relu_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float* save_mean,
                        float* save_rstd, float* stats_ws, int rows, int c, float momentum,
@@ -96,7 +99,8 @@ void bn_relu_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const 
                       const float* running_mean, const float* running_var, int rows, int c,
                       float eps, hipStream_t stream);
 // dx, dgamma, dbeta from dy (grad of the ReLU output), the saved input x and statistics.
-// `stats_ws` is 2*c floats of scratch; dgamma/dbeta are overwritten.
+// `stats_ws` as above; dgamma/dbeta are overwritten.
+size_t bn_workspace_elems();
 void bn_relu_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
                  const float* beta, const float* save_mean, const float* save_rstd,
                  float* dgamma, float* dbeta, float* stats_ws, int rows, int c,

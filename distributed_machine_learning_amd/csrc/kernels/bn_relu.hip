@@ -6,13 +6,15 @@
 // with the unbiased one; evaluation folds the running statistics into a scale/shift.
 //
 // In NHWC a channel is a column of the [rows = B*H*W][c] matrix, so the statistics are
-// column reductions: each block walks a strided slab of rows with 16-byte loads (8
-// channels per thread), reduces its row lanes through LDS and adds one fp32 partial per
-// column with an atomic.  Apply kernels re-derive scale/shift per thread from the tiny
-// per-channel vectors and stream the tensor once.  All statistics stay fp32.
+// column reductions (dml_column_reduce.h): blocks stream row slabs with 16-byte loads (8
+// channels per thread) and store partial sums, a small second kernel folds the partials
+// and finalises (mean / rstd / running statistics forward, dgamma / dbeta backward) - no
+// memset, no result atomics.  The apply kernels then stream the tensor once with
+// per-channel constants held in registers.  All statistics stay fp32.
 #include <stdexcept>
 #include <string>
 
+#include "dml_column_reduce.h"
 #include "dml_common.h"
 #include "dml_kernels.h"
 
@@ -20,65 +22,26 @@ namespace dml {
 
 namespace {
 
-constexpr int kMaxBlocks = 1024;
-
-struct RowSplit { int blocks, rows_per_block; };
-
-// Enough blocks to fill the chip, but at least 4 rows per row lane (256 / (c/8) lanes per
-// block) so the LDS reduction and the atomics stay a small fraction of the work.
-RowSplit split_rows(int rows, int c) {
-    const int lanes = 256 / (c / 8);
-    int rpb = (rows + kMaxBlocks - 1) / kMaxBlocks;
-    if (rpb < 4 * lanes) rpb = 4 * lanes;
-    return {(rows + rpb - 1) / rpb, rpb};
-}
-
 void check(int rows, int c, const char* who) {
     if (c % 8 || c < 8 || c > 2048 || (256 % (c / 8)) != 0 || rows <= 0)
         throw std::invalid_argument(std::string(who) + ": c must be 8*2^k <= 2048 and rows > 0");
 }
 
-// two column reductions at once: ws[col] += sum a, ws[c + col] += sum b
-template <typename F>
-__device__ __forceinline__ void reduce_columns2(F&& row_values, float* ws, int rows, int c,
-                                                int rows_per_block, float* red) {
-    const int c8 = c / 8, lanes = 256 / c8;
-    const int cg = threadIdx.x % c8, rl = threadIdx.x / c8;
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(rows, r0 + rows_per_block);
-    float a[8], b[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = b[i] = 0.f;
-    int r = r0 + rl;
-    for (; r + lanes < r1; r += 2 * lanes) {       // two rows in flight per thread
-        row_values(r, cg, a, b);
-        row_values(r + lanes, cg, a, b);
-    }
-    for (; r < r1; r += lanes) row_values(r, cg, a, b);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        red[threadIdx.x * 8 + i] = a[i];
-        red[2048 + threadIdx.x * 8 + i] = b[i];
-    }
-    __syncthreads();
-    for (int col = threadIdx.x; col < 2 * c; col += 256) {
-        const int which = col >= c ? 1 : 0;
-        const int cc = col - which * c;
-        const int g = cc / 8, i = cc % 8;
-        float s = 0.f;
-        for (int l = 0; l < lanes; ++l) s += red[which * 2048 + (l * c8 + g) * 8 + i];
-        atomicAdd(ws + col, s);
-    }
+unsigned apply_blocks(size_t total8) {
+    size_t blocks = (total8 + 255) / 256;
+    return (unsigned)(blocks > 2048 ? 2048 : blocks);
 }
 
 }  // namespace
+
+size_t bn_workspace_elems() { return kColReduceWsFloats; }
 
 // ----------------------------------------------------------------- forward, training
 __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restrict__ x,
                                                        float* __restrict__ ws, int rows, int c,
                                                        int rows_per_block) {
     __shared__ float red[4096];
-    reduce_columns2(
+    column_partials(
         [&](int r, int cg, float (&a)[8], float (&b)[8]) {
             float v[8];
             unpack8(*(const uint4*)(x + (size_t)r * c + cg * 8), v);
@@ -88,16 +51,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restric
         ws, rows, c, rows_per_block, red);
 }
 
-__global__ __launch_bounds__(256) void bn_apply_train_kernel(
-    const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ running_mean,
-    float* __restrict__ running_var, float* __restrict__ save_mean, float* __restrict__ save_rstd,
-    const float* __restrict__ ws, int rows, int c, float momentum, float eps, size_t total8) {
+__global__ __launch_bounds__(256) void bn_stats_finish_kernel(
+    const float* __restrict__ ws, float* __restrict__ save_mean, float* __restrict__ save_rstd,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int nb, int rows, int c,
+    float momentum, float eps) {
     const float inv_n = 1.f / (float)rows;
-    if (blockIdx.x == 0) {
-        for (int col = threadIdx.x; col < c; col += 256) {
-            const float mean = ws[col] * inv_n;
-            const float var = fmaxf(ws[c + col] * inv_n - mean * mean, 0.f);
+    column_fold(
+        [&](int col, float s1, float s2) {
+            const float mean = s1 * inv_n;
+            const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
             save_mean[col] = mean;
             save_rstd[col] = rsqrtf(var + eps);
             if (running_mean) {
@@ -105,62 +67,65 @@ __global__ __launch_bounds__(256) void bn_apply_train_kernel(
                 running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mean;
                 running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
             }
-        }
-    }
+        },
+        ws, nb, c);
+}
+
+// y = relu(x * scale + shift) with scale = gamma * rstd, shift = beta - mean * scale.  A
+// thread's 8 channels are the same in every grid-stride iteration (the stride is a multiple
+// of c/8), so the per-channel constants are loaded once as 16-byte vectors; the streaming
+// loop is load - fma - max - store with no branches.
+template <bool FROM_VAR>
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ rstd_or_var, int c, float eps, size_t total8) {
     const int c8 = c / 8;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int col = (int)(i % c8) * 8;
+    float sc[8], sh[8];
+    {
+        const float4 g0 = *(const float4*)(gamma + col), g1 = *(const float4*)(gamma + col + 4);
+        const float4 b0 = *(const float4*)(beta + col), b1 = *(const float4*)(beta + col + 4);
+        const float4 m0 = *(const float4*)(mean + col), m1 = *(const float4*)(mean + col + 4);
+        const float4 r0 = *(const float4*)(rstd_or_var + col),
+                     r1 = *(const float4*)(rstd_or_var + col + 4);
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        const float rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float rs = FROM_VAR ? rsqrtf(rr[k] + eps) : rr[k];
+            sc[k] = g[k] * rs;
+            sh[k] = bb[k] - m[k] * sc[k];
+        }
+    }
     for (; i < total8; i += stride) {
-        const int col = (int)(i % c8) * 8;
         float v[8], o[8];
         unpack8(*(const uint4*)(x + i * 8), v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float mean = ws[col + k] * inv_n;
-            const float var = fmaxf(ws[c + col + k] * inv_n - mean * mean, 0.f);
-            const float sc = gamma[col + k] * rsqrtf(var + eps);
-            o[k] = fmaxf((v[k] - mean) * sc + beta[col + k], 0.f);
-        }
+        for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
         *(uint4*)(y + i * 8) = pack8(o);
     }
 }
 
 void bn_relu_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float* save_mean,
-                       float* save_rstd, float* stats_ws, int rows, int c, float momentum,
+                       float* save_rstd, float* ws, int rows, int c, float momentum,
                        float eps, hipStream_t stream) {
     check(rows, c, "bn_relu_fwd_train");
-    (void)hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * c, stream);
-    const RowSplit rs = split_rows(rows, c);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(rs.blocks), dim3(256), 0, stream, x, stats_ws, rows,
-                       c, rs.rows_per_block);
+    const ColReducePlan pl = plan_col_reduce(rows, c);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, c,
+                       pl.rows_per_block);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((c + 63) / 64), dim3(256), 0, stream,
+                       (const float*)ws, save_mean, save_rstd, running_mean, running_var, pl.blocks,
+                       rows, c, momentum, eps);
     const size_t total8 = (size_t)rows * (c / 8);
-    size_t blocks = (total8 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bn_apply_train_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y,
-                       gamma, beta, running_mean, running_var, save_mean, save_rstd, stats_ws, rows,
-                       c, momentum, eps, total8);
-}
-
-// --------------------------------------------------------------- forward, evaluation
-__global__ __launch_bounds__(256) void bn_apply_eval_kernel(
-    const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ rm, const float* __restrict__ rv,
-    int c, float eps, size_t total8) {
-    const int c8 = c / 8;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < total8; i += stride) {
-        const int col = (int)(i % c8) * 8;
-        float v[8], o[8];
-        unpack8(*(const uint4*)(x + i * 8), v);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float sc = gamma[col + k] * rsqrtf(rv[col + k] + eps);
-            o[k] = fmaxf((v[k] - rm[col + k]) * sc + beta[col + k], 0.f);
-        }
-        *(uint4*)(y + i * 8) = pack8(o);
-    }
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(apply_blocks(total8)), dim3(256), 0, stream, x,
+                       y, gamma, beta, (const float*)save_mean, (const float*)save_rstd, c, eps,
+                       total8);
 }
 
 void bn_relu_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
@@ -168,10 +133,8 @@ void bn_relu_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const 
                       float eps, hipStream_t stream) {
     check(rows, c, "bn_relu_fwd_eval");
     const size_t total8 = (size_t)rows * (c / 8);
-    size_t blocks = (total8 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bn_apply_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y,
-                       gamma, beta, running_mean, running_var, c, eps, total8);
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(apply_blocks(total8)), dim3(256), 0, stream, x,
+                       y, gamma, beta, running_mean, running_var, c, eps, total8);
 }
 
 // -------------------------------------------------------------------------- backward
@@ -183,49 +146,82 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ ws,
     int rows, int c, int rows_per_block) {
     __shared__ float red[4096];
-    reduce_columns2(
+    // this thread's 8 channels are fixed: y > 0  <=>  x * ysc + ysh > 0, xh = x * rs - mrs
+    float rs[8], mrs[8], ysc[8], ysh[8];
+    {
+        const int col0 = (threadIdx.x % (c / 8)) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            rs[i] = rstd[col0 + i];
+            mrs[i] = mean[col0 + i] * rs[i];
+            ysc[i] = gamma[col0 + i] * rs[i];
+            ysh[i] = beta[col0 + i] - gamma[col0 + i] * mrs[i];
+        }
+    }
+    column_partials(
         [&](int r, int cg, float (&a)[8], float (&b)[8]) {
             float v[8], g[8];
             unpack8(*(const uint4*)(x + (size_t)r * c + cg * 8), v);
             unpack8(*(const uint4*)(dy + (size_t)r * c + cg * 8), g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int col = cg * 8 + i;
-                const float xh = (v[i] - mean[col]) * rstd[col];
-                const float gi = (gamma[col] * xh + beta[col] > 0.f) ? g[i] : 0.f;
+                const float gi = (v[i] * ysc[i] + ysh[i] > 0.f) ? g[i] : 0.f;
                 a[i] += gi;
-                b[i] += gi * xh;
+                b[i] += gi * (v[i] * rs[i] - mrs[i]);
             }
         },
         ws, rows, c, rows_per_block, red);
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ ws,
+                                                            float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int nb,
+                                                            int c) {
+    column_fold(
+        [&](int col, float s1, float s2) {
+            dbeta[col] = s1;
+            dgamma[col] = s2;
+        },
+        ws, nb, c);
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
     const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ ws,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int c, size_t total8) {
-    if (blockIdx.x == 0) {
-        for (int col = threadIdx.x; col < c; col += 256) {
-            dbeta[col] = ws[col];
-            dgamma[col] = ws[c + col];
-        }
-    }
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ dgamma, const float* __restrict__ dbeta, int rows, int c,
+    size_t total8) {
     const float inv_n = 1.f / (float)rows;
     const int c8 = c / 8;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < total8; i += stride) {
+    // per-thread channel constants (fixed across the grid-stride loop):
+    //   dx = k1 * g - k2 - k3 * x   with xh = x*rs - mrs folded in
+    float rs[8], ysc[8], ysh[8], k1[8], k2[8], k3[8];
+    {
         const int col0 = (int)(i % c8) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int col = col0 + k;
+            rs[k] = rstd[col];
+            const float mrs = mean[col] * rs[k];
+            ysc[k] = gamma[col] * rs[k];
+            ysh[k] = beta[col] - gamma[col] * mrs;
+            k1[k] = gamma[col] * rs[k];
+            const float dg = dgamma[col] * inv_n, db = dbeta[col] * inv_n;
+            // k1 * (g - db - (x*rs - mrs) * dg) = k1*g - k1*(db - mrs*dg) - (k1*rs*dg) * x
+            k2[k] = k1[k] * (db - mrs * dg);
+            k3[k] = k1[k] * rs[k] * dg;
+        }
+    }
+    for (; i < total8; i += stride) {
         float v[8], g[8], o[8];
         unpack8(*(const uint4*)(x + i * 8), v);
         unpack8(*(const uint4*)(dy + i * 8), g);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int col = col0 + k;
-            const float xh = (v[k] - mean[col]) * rstd[col];
-            const float gi = (gamma[col] * xh + beta[col] > 0.f) ? g[k] : 0.f;
-            o[k] = gamma[col] * rstd[col] * (gi - ws[col] * inv_n - xh * ws[c + col] * inv_n);
+            const float gi = (v[k] * ysc[k] + ysh[k] > 0.f) ? g[k] : 0.f;
+            o[k] = k1[k] * gi - k2[k] - k3[k] * v[k];
         }
         *(uint4*)(dx + i * 8) = pack8(o);
     }
@@ -233,18 +229,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 
 void bn_relu_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
                  const float* beta, const float* save_mean, const float* save_rstd,
-                 float* dgamma, float* dbeta, float* stats_ws, int rows, int c,
-                 hipStream_t stream) {
+                 float* dgamma, float* dbeta, float* ws, int rows, int c, hipStream_t stream) {
     check(rows, c, "bn_relu_bwd");
-    (void)hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * c, stream);
-    const RowSplit rs = split_rows(rows, c);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rs.blocks), dim3(256), 0, stream, x, dy, gamma,
-                       beta, save_mean, save_rstd, stats_ws, rows, c, rs.rows_per_block);
+    const ColReducePlan pl = plan_col_reduce(rows, c);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, dy, gamma,
+                       beta, save_mean, save_rstd, ws, rows, c, pl.rows_per_block);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((c + 63) / 64), dim3(256), 0, stream,
+                       (const float*)ws, dgamma, dbeta, pl.blocks, c);
     const size_t total8 = (size_t)rows * (c / 8);
-    size_t blocks = (total8 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, dy, dx,
-                       gamma, beta, save_mean, save_rstd, stats_ws, dgamma, dbeta, rows, c, total8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(total8)), dim3(256), 0, stream, x, dy,
+                       dx, gamma, beta, save_mean, save_rstd, (const float*)dgamma,
+                       (const float*)dbeta, rows, c, total8);
 }
 
 }  // namespace dml

@@ -144,8 +144,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2c1;
 
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __restrict__ x,
                                                           const uint16_t* __restrict__ dy,
-                                                          float* __restrict__ dw,
-                                                          float* __restrict__ db, int M,
+                                                          float* __restrict__ slab, int M,
                                                           int steps_per_block) {
     constexpr int S = 192;
     constexpr int PX = 128;                      // pixels per step
@@ -243,29 +242,71 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
             __syncthreads();
         }
     }
-    // D[co][k]: lane -> k = tk*32 + (l & 31); register r -> co
+    // D[co][k]: lane -> k = tk*32 + (l & 31); register r -> co.  Each block stores its
+    // partial [64 co][40 k] tile; conv1_wgrad_finish_kernel folds the blocks (all blocks
+    // adding into the same 1792 addresses with atomics would serialise at the memory side).
     const int k = tk * 32 + (lane & 31), lh = lane >> 5;
-    const int tap = k >> 2, c = k & 3;
+    if (k < 40) {
+        float* dst = slab + (size_t)blockIdx.x * (64 * 40) + k;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = tco * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (tap < 9 && c < 3) atomicAdd(dw + co * 27 + tap * 3 + c, acc[r]);
-        else if (k == 36 && db) atomicAdd(db + co, acc[r]);
+        for (int r = 0; r < 16; ++r) {
+            const int co = tco * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            dst[co * 40] = acc[r];
+        }
     }
 }
 
-void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, int batch,
-                 hipStream_t stream) {
-    if (batch <= 0) return;
-    if ((long long)batch * 1024 * 128 >= (1LL << 31))
-        throw std::invalid_argument("conv1_wgrad: batch too large");
-    const int M = batch * 1024;
+// dw[co][tap][c] += sum_blocks slab[b][co][tap*4+c] (c < 3), db[co] += sum_blocks slab[b][co][36].
+// Grid: 40 blocks of 64 outputs; 4 lanes per output each fold a quarter of the slab rows.
+__global__ __launch_bounds__(256) void conv1_wgrad_finish_kernel(const float* __restrict__ slab,
+                                                                 float* __restrict__ dw,
+                                                                 float* __restrict__ db,
+                                                                 int nblocks) {
+    __shared__ float red[4][64];
+    const int o = blockIdx.x * 64 + (threadIdx.x & 63);      // 0 .. 2559 = co * 40 + k
+    const int part = threadIdx.x >> 6;
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = part; b < nblocks; b += 4) s += slab[(size_t)b * 2560 + o];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                        red[3][threadIdx.x];
+        const int co = o / 40, k = o % 40;
+        const int tap = k >> 2, c = k & 3;
+        if (tap < 9 && c < 3) dw[co * 27 + tap * 3 + c] += v;
+        else if (k == 36 && db) db[co] += v;
+    }
+}
+
+namespace {
+int conv1_wgrad_blocks(int M, int* steps_per_block) {
     const int total_steps = (M + 127) / 128;
     int blocks = total_steps < 512 ? total_steps : 512;
     const int spb = (total_steps + blocks - 1) / blocks;
-    blocks = (total_steps + spb - 1) / spb;
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, dw, db, M,
-                       spb);
+    *steps_per_block = spb;
+    return (total_steps + spb - 1) / spb;
+}
+}  // namespace
+
+size_t conv1_wgrad_workspace_elems(int batch) {
+    int spb;
+    return (size_t)conv1_wgrad_blocks(batch * 1024, &spb) * 2560;
+}
+
+void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, int batch,
+                 float* ws, hipStream_t stream) {
+    if (batch <= 0) return;
+    if ((long long)batch * 1024 * 128 >= (1LL << 31))
+        throw std::invalid_argument("conv1_wgrad: batch too large");
+    if (!ws) throw std::invalid_argument("conv1_wgrad: workspace missing");
+    const int M = batch * 1024;
+    int spb;
+    const int blocks = conv1_wgrad_blocks(M, &spb);
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, ws, M, spb);
+    hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(40), dim3(256), 0, stream,
+                       (const float*)ws, dw, db, blocks);
 }
 
 }  // namespace dml

@@ -9,6 +9,7 @@
 // All of these are memory-bound: every thread moves 16-byte vectors (8 bf16 channels).
 #include <stdexcept>
 
+#include "dml_column_reduce.h"
 #include "dml_common.h"
 #include "dml_kernels.h"
 
@@ -96,66 +97,40 @@ void maxpool2x2_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, int bat
 }
 
 // ----------------------------------------------------------------------- column sum
-// out[c] += sum over rows.  Block = 256 threads = (256 / (c/8)) row lanes x (c/8) column
-// groups; each block walks a strided slab of rows, reduces across its row lanes in LDS and
-// issues one atomic per column.
+// out[c] += sum over rows (bias gradients): partial rows per block, then a small fold
+// kernel (dml_column_reduce.h); no atomics on `out`.
 __global__ __launch_bounds__(256) void column_sum_kernel(const uint16_t* __restrict__ x,
-                                                         float* __restrict__ out, int rows, int c,
+                                                         float* __restrict__ ws, int rows, int c,
                                                          int rows_per_block) {
-    __shared__ float red[256 * 8];
-    const int c8 = c / 8;                 // 8 .. 64 column groups
-    const int lanes = 256 / c8;           // row lanes per block
-    const int cg = threadIdx.x % c8, rl = threadIdx.x / c8;
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(rows, r0 + rows_per_block);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (rl < lanes) {
-        // four independent 16-byte loads in flight per thread
-        int r = r0 + rl;
-        for (; r + 3 * lanes < r1; r += 4 * lanes) {
-            uint4 q[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                q[u] = *(const uint4*)(x + (size_t)(r + u * lanes) * c + cg * 8);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float v[8];
-                unpack8(q[u], v);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] += v[i];
-            }
-        }
-        for (; r < r1; r += lanes) {
+    __shared__ float red[4096];
+    column_partials(
+        [&](int r, int cg, float (&a)[8], float (&b)[8]) {
             float v[8];
             unpack8(*(const uint4*)(x + (size_t)r * c + cg * 8), v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += v[i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = (rl < lanes) ? acc[i] : 0.f;
-    __syncthreads();
-    // thread t < c sums column t over the row lanes
-    for (int col = threadIdx.x; col < c; col += 256) {
-        const int g = col / 8, i = col % 8;
-        float s = 0.f;
-        for (int l = 0; l < lanes; ++l) s += red[(l * c8 + g) * 8 + i];
-        atomicAdd(out + col, s);
-    }
+            for (int i = 0; i < 8; ++i) a[i] += v[i];
+        },
+        ws, rows, c, rows_per_block, red);
 }
 
-void column_sum(const bf16_raw* x, float* out, int rows, int cols, hipStream_t stream) {
+__global__ __launch_bounds__(256) void column_sum_finish_kernel(const float* __restrict__ ws,
+                                                                float* __restrict__ out, int nb,
+                                                                int c) {
+    column_fold([&](int col, float s1, float) { out[col] += s1; }, ws, nb, c);
+}
+
+size_t column_sum_workspace_elems() { return kColReduceWsFloats; }
+
+void column_sum(const bf16_raw* x, float* out, int rows, int cols, float* ws, hipStream_t stream) {
     if (cols % 8 || cols < 8 || cols > 2048 || (256 % (cols / 8)) != 0)
         throw std::invalid_argument("column_sum: cols must be 8*2^k, <= 2048");
+    if (!ws) throw std::invalid_argument("column_sum: workspace missing");
     if (rows <= 0) return;
-    // enough blocks to fill the chip, but at least 4 rows per row lane so the per-block
-    // reduction and its atomics stay a small fraction of the work
-    const int lanes = 256 / (cols / 8);
-    int rpb = (rows + 1023) / 1024;
-    if (rpb < 4 * lanes) rpb = 4 * lanes;
-    const int blocks = (rows + rpb - 1) / rpb;
-    hipLaunchKernelGGL(column_sum_kernel, dim3(blocks), dim3(256), 0, stream, x, out, rows, cols,
-                       rpb);
+    const ColReducePlan pl = plan_col_reduce(rows, cols);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, cols,
+                       pl.rows_per_block);
+    hipLaunchKernelGGL(column_sum_finish_kernel, dim3((cols + 63) / 64), dim3(256), 0, stream,
+                       (const float*)ws, out, pl.blocks, cols);
 }
 
 // ------------------------------------------------------------- augmentation + normalise

@@ -170,7 +170,9 @@ def conv1_wgrad(x4: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Tensor, torch
         raise ValueError("conv1_wgrad: shape mismatch")
     dw = torch.zeros(64, 3, 3, 3, dtype=torch.float32, device=x4.device)
     db = torch.zeros(64, dtype=torch.float32, device=x4.device)
-    lib().conv1_wgrad(x4.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), b, _stream())
+    ws = torch.empty(lib().conv1_wgrad_workspace_elems(b), dtype=torch.float32, device=x4.device)
+    lib().conv1_wgrad(x4.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), b,
+                      ws.data_ptr(), _stream())
     return dw, db
 
 
@@ -179,8 +181,22 @@ def column_sum(x: torch.Tensor) -> torch.Tensor:
     _req(x, torch.bfloat16, "x")
     c = x.shape[-1]
     out = torch.zeros(c, dtype=torch.float32, device=x.device)
-    lib().column_sum(x.data_ptr(), out.data_ptr(), x.numel() // c, c, _stream())
+    lib().column_sum(x.data_ptr(), out.data_ptr(), x.numel() // c, c, _reduce_ws(x.device).data_ptr(),
+                     _stream())
     return out
+
+
+_REDUCE_WS = {}
+
+
+def _reduce_ws(device) -> torch.Tensor:
+    """Scratch of the in-launch column reductions (zero before first use; every launch
+    leaves its ticket counter at zero again).  One per device and stream-ordered use."""
+    key = (device.type, device.index)
+    if key not in _REDUCE_WS:
+        _REDUCE_WS[key] = torch.zeros(lib().column_reduce_workspace_elems(), dtype=torch.float32,
+                                      device=device)
+    return _REDUCE_WS[key]
 
 
 # --------------------------------------------------------------------------- pool
@@ -217,7 +233,7 @@ def bn_relu_fwd_train(x, gamma, beta, running_mean=None, running_var=None, momen
     y = torch.empty_like(x)
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     rstd = torch.empty(c, dtype=torch.float32, device=x.device)
-    ws = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    ws = _reduce_ws(x.device)
     lib().bn_relu_fwd_train(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                             _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
                             rstd.data_ptr(), ws.data_ptr(), rows, c, momentum, eps, _stream())
@@ -242,7 +258,7 @@ def bn_relu_bwd(x, dy, gamma, beta, save_mean, save_rstd):
     dx = torch.empty_like(x)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
-    ws = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    ws = _reduce_ws(x.device)
     lib().bn_relu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                       save_mean.data_ptr(), save_rstd.data_ptr(), dgamma.data_ptr(),
                       dbeta.data_ptr(), ws.data_ptr(), x.numel() // c, c, _stream())
