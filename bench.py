@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--bucket-cap-mb", type=float, default=25.0)
     ap.add_argument("--serialize-streams", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="build the RCCL communicator and sync strategy even with one rank")
     return ap.parse_args()
 
 
@@ -75,9 +77,10 @@ def main():
     from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
 
     batch_norm = ns.batch_norm if ns.batch_norm is not None else (ns.mode == "part3")
-    sync = MODE_SYNC[ns.mode] if world > 1 else "none"
+    use_comm = world > 1 or ns.force_comm
+    sync = MODE_SYNC[ns.mode] if use_comm else "none"
     master = f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{os.environ.get('MASTER_PORT', '29500')}"
-    comm = RcclCommunicator(master, rank, world, local_rank, timeout_s=120) if world > 1 else None
+    comm = RcclCommunicator(master, rank, world, local_rank, timeout_s=120) if use_comm else None
 
     cfg = TrainConfig(master_ip=master, rank=rank, num_nodes=world, sync=sync,
                       batch_size=ns.batch_size, batch_norm=batch_norm, dtype=ns.dtype,
