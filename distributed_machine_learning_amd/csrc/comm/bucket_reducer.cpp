@@ -49,6 +49,8 @@ BucketReducer::BucketReducer(RcclComm* comm, float* flat_grads, std::vector<Slic
     : comm_(comm), grads_(flat_grads), slices_(std::move(slices)), average_(average),
       serialize_(serialize) {
     if (!comm_) throw std::invalid_argument("BucketReducer: communicator missing");
+    // Default priority on purpose: with a high-priority communication stream the
+    // event hand-off with the compute stream was observed to stall on MI355X / ROCm 7.
     if (!serialize_)
         check_hip(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking), "hipStreamCreate");
     ready_.resize(slices_.size());
@@ -63,6 +65,7 @@ BucketReducer::BucketReducer(RcclComm* comm, float* flat_grads, std::vector<Slic
 BucketReducer::~BucketReducer() {
     for (auto e : ready_) (void)hipEventDestroy(e);
     for (auto e : done_) (void)hipEventDestroy(e);
+    if (buffers_done_) (void)hipEventDestroy(buffers_done_);
     if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
 }
 
@@ -81,6 +84,12 @@ void BucketReducer::bucket_ready(int b, hipStream_t compute) {
     check_hip(hipStreamWaitEvent(comm_stream_, ready_[b], 0), "hipStreamWaitEvent(comm)");
     comm_->all_reduce(grads_ + s.offset, s.count, DT_F32, average_, comm_stream_);
     check_hip(hipEventRecord(done_[b], comm_stream_), "hipEventRecord(done)");
+    if (buffers_to_send_) {
+        buffers_to_send_ = false;
+        comm_->broadcast(buffers_, buffers_shadow_, buffers_count_, DT_F32, 0, comm_stream_);
+        check_hip(hipEventRecord(buffers_done_, comm_stream_), "hipEventRecord(buffers done)");
+        buffers_pending_ = true;
+    }
 }
 
 void BucketReducer::wait_all(hipStream_t compute) {
@@ -91,6 +100,39 @@ void BucketReducer::wait_all(hipStream_t compute) {
         if (!serialize_)
             check_hip(hipStreamWaitEvent(compute, done_[b], 0), "hipStreamWaitEvent(compute)");
     }
+}
+
+void BucketReducer::set_buffer_sync(float* buffers, float* shadow, size_t count) {
+    if (count && (!buffers || !shadow))
+        throw std::invalid_argument("BucketReducer: buffer sync needs both pointers");
+    buffers_ = buffers;
+    buffers_shadow_ = shadow;
+    buffers_count_ = count;
+    buffers_pending_ = buffers_to_send_ = false;
+    if (count && !buffers_done_)
+        check_hip(hipEventCreateWithFlags(&buffers_done_, hipEventDisableTiming), "hipEventCreate");
+}
+
+void BucketReducer::buffers_updated(hipStream_t) {
+    // Forward is done, so rank 0's statistics are final.  The broadcast itself rides along
+    // with the first bucket of this backward (one event hand-off fewer); in debug mode it
+    // happens in place at the next step's start.
+    if (!buffers_count_) return;
+    if (serialize_) buffers_pending_ = true;
+    else buffers_to_send_ = true;
+}
+
+void BucketReducer::apply_buffers(hipStream_t compute) {
+    if (!buffers_count_ || !buffers_pending_) return;
+    buffers_pending_ = false;
+    if (serialize_) {
+        comm_->broadcast(buffers_, buffers_count_, DT_F32, 0, compute);
+        return;
+    }
+    check_hip(hipStreamWaitEvent(compute, buffers_done_, 0), "hipStreamWaitEvent(buffers)");
+    check_hip(hipMemcpyAsync(buffers_, buffers_shadow_, buffers_count_ * sizeof(float),
+                             hipMemcpyDeviceToDevice, compute),
+              "hipMemcpyAsync(buffers)");
 }
 
 // ----------------------------------------------------------------------- bindings
@@ -172,6 +214,14 @@ void bind_comm(py::module_& m) {
             r.bucket_ready(b, (hipStream_t)s);
         })
         .def("wait_all", [](BucketReducer& r, uintptr_t s) { r.wait_all((hipStream_t)s); })
+        .def("set_buffer_sync", [](BucketReducer& r, uintptr_t buf, uintptr_t shadow, size_t n) {
+            r.set_buffer_sync((float*)buf, (float*)shadow, n);
+        })
+        .def("buffers_updated", [](BucketReducer& r, uintptr_t s) {
+            r.buffers_updated((hipStream_t)s);
+        })
+        .def("apply_buffers", [](BucketReducer& r, uintptr_t s) { r.apply_buffers((hipStream_t)s); })
+        .def("drop_pending_buffers", &BucketReducer::drop_pending_buffers)
         .def_property_readonly("comm_stream",
                                [](BucketReducer& r) { return (uintptr_t)r.comm_stream(); });
 }

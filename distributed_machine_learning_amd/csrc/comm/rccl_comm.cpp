@@ -109,6 +109,13 @@ void RcclComm::broadcast(void* buf, size_t count, DType dt, int root, hipStream_
                "ncclBroadcast");
 }
 
+void RcclComm::broadcast(const void* send, void* recv, size_t count, DType dt, int root,
+                         hipStream_t stream) {
+    if (count == 0) return;
+    check_nccl(ncclBroadcast(send, recv, count, nccl_type(dt), root, (ncclComm_t)comm_, stream),
+               "ncclBroadcast");
+}
+
 void RcclComm::gather(const void* send, const std::vector<void*>& recv, size_t count, DType dt,
                       int root, hipStream_t stream) {
     if (count == 0) return;

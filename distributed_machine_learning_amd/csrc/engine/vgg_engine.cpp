@@ -312,8 +312,12 @@ void VggEngine::forward_backward(const uint16_t* x, const int64_t* target, int b
     if (!params_) throw std::logic_error("VggEngine: bind() first");
     check_hip(hipMemsetAsync(grads_, 0, param_elems_ * sizeof(float), stream), "memset(grads)");
     check_hip(hipMemsetAsync(ws_ + loss_off_, 0, sizeof(float), stream), "memset(loss)");
-    if (reducer_) reducer_->begin_step();
+    if (reducer_) {
+        reducer_->begin_step();
+        reducer_->apply_buffers(stream);        // running statistics := rank 0's
+    }
     forward(x, batch, true, stream);
+    if (reducer_ && bn_) reducer_->buffers_updated(stream);
     backward(x, target, batch, stream);
 }
 

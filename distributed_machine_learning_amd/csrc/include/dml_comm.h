@@ -70,6 +70,9 @@ class RcclComm {
 
     void all_reduce(void* buf, size_t count, DType dt, bool average, hipStream_t stream);
     void broadcast(void* buf, size_t count, DType dt, int root, hipStream_t stream);
+    // out-of-place form: root sends `send`, every rank (root included) receives into `recv`
+    void broadcast(const void* send, void* recv, size_t count, DType dt, int root,
+                   hipStream_t stream);
     // root receives rank r's `send` into recv[r]; its own contribution is a device copy
     void gather(const void* send, const std::vector<void*>& recv, size_t count, DType dt,
                 int root, hipStream_t stream);
@@ -105,6 +108,13 @@ std::vector<BucketRange> plan_buckets(const std::vector<size_t>& sizes_bytes, si
 // enqueues the all-reduce of that slice in place; `wait_all(compute)` makes the compute
 // stream wait for every outstanding bucket (called right before the optimizer kernel).
 // No host synchronisation, no staging copies.
+//
+// Module buffers (BatchNorm running statistics) follow rank 0 the way
+// DistributedDataParallel(broadcast_buffers=True) makes them: every forward starts from
+// rank 0's values.  Rank 0's buffers are final once its forward has run, so the broadcast
+// is issued on the communication stream behind the first bucket of the same step, into a
+// shadow copy (hidden under backward), and the next step copies the shadow over the live
+// buffers before its forward.
 class BucketReducer {
   public:
     struct Slice { size_t offset, count; };
@@ -117,6 +127,11 @@ class BucketReducer {
     void wait_all(hipStream_t compute);
     hipStream_t comm_stream() const { return comm_stream_; }
 
+    void set_buffer_sync(float* buffers, float* shadow, size_t count);
+    void buffers_updated(hipStream_t compute);      // call after the forward pass
+    void apply_buffers(hipStream_t compute);        // call before the next forward pass
+    void drop_pending_buffers() { buffers_pending_ = buffers_to_send_ = false; }
+
   private:
     RcclComm* comm_;
     float* grads_;
@@ -125,6 +140,11 @@ class BucketReducer {
     hipStream_t comm_stream_ = nullptr;
     std::vector<hipEvent_t> ready_, done_;
     std::vector<char> launched_;
+    float* buffers_ = nullptr;
+    float* buffers_shadow_ = nullptr;
+    size_t buffers_count_ = 0;
+    bool buffers_pending_ = false, buffers_to_send_ = false;
+    hipEvent_t buffers_done_ = nullptr;
 };
 
 void bind_comm(pybind11::module_& m);

@@ -6,25 +6,31 @@
 //
 //   y[m][n] = sum_{tap, c} x[m (+) tap][c] * w[n][tap][c]        m = (b, h, w), NHWC
 //
-// GEMM view: M = B*H*W pixels, N = output channels, K = 9 * C ordered tap-major so one
-// 64-wide K step lies inside one tap.  The "A" side (pixels) is gathered on the fly
-// (im2col never exists in memory): every thread owns fixed pixel rows of the tile and per
-// tap only re-derives the halo predicate and a constant offset.  Backward-data is the
-// same kernel run on dy with the tap-flipped, channel-transposed weights.
+// GEMM view: M = B*H*W pixels, N = output channels, K = 9 * C walked chunk-outer /
+// tap-inner in 64-channel steps (consecutive steps re-read neighbouring pixels of the same
+// 64 channels, which stay in L2).  The "A" side (pixels) is gathered on the fly - im2col
+// never exists in memory: every thread owns fixed pixel rows of the tile and per tap only
+// re-derives the halo predicate and a constant offset.  Backward-data is the same kernel
+// run on dy with the tap-flipped, channel-transposed weights.
 //
 // CDNA4 mapping
-//   * 256 threads = 4 wave64; block tile BM x BN, K step 64, wave tile (BM/WM) x (BN/WN)
-//     built from v_mfma_f32_16x16x32_bf16 with fp32 accumulators.
+//   * 256 threads = 4 wave64; block tile BM x BN (128x128, 128x64 or 64x64), K step 64,
+//     wave tiles built from v_mfma_f32_16x16x32_bf16 with fp32 accumulators.
 //   * The weight tile is fed as the MFMA *A* operand and the pixel tile as *B*, so the
 //     accumulator layout is D[n][m]: a lane holds 4 consecutive output channels of one
 //     pixel, which makes the epilogue (bias, ReLU, ReLU-mask, bf16 pack) an 8-byte
 //     vector store into NHWC with no shuffles.
-//   * Operand tiles live in LDS as 128-byte rows (64 bf16 of K).  16-byte chunks are
-//     XOR-swizzled with (row >> 1) & 7 so the 16 rows x 2 chunks touched by one
-//     ds_read_b128 lane group fall on 16 distinct 16-byte bank slots.
-//   * Global -> register -> LDS staging with two LDS stages: the loads of step s+1 are
-//     issued before the MFMAs of step s and written to the other stage after them; one
-//     barrier per K step.
+//   * Global -> LDS without registers: buffer loads with the LDS-destination form write a
+//     wave's 64 x 16 bytes as one linear 1 KiB LDS image.  Operand tiles are 128-byte rows
+//     (64 bf16 of K); the bank swizzle chunk ^ ((row >> 1) & 7) is applied on the SOURCE
+//     side (each lane fetches the global chunk that belongs in its fixed LDS slot), so the
+//     ds_read_b128 fragment reads stay conflict-free.
+//   * Halo pixels and rows past the end of the tensor are not branched on: their lanes use
+//     a voffset beyond the buffer descriptor's extent and the hardware returns zeros.
+//   * NS-stage LDS ring (3 or 4 stages by tile size) with counted waits: step s waits with
+//     s_waitcnt vmcnt((D-1) * loads_per_stage) for its own stage only, one raw s_barrier,
+//     then issues the loads of step s+D-1... and runs the MFMAs of step s, so D-1 stages of
+//     HBM/L2 latency are always in flight behind the matrix cores.
 //   * Layers whose M x N grid cannot fill 256 CUs split the reduction over taps
 //     (blockIdx.y); partial tiles go to an fp32 slab per split with plain stores and a
 //     small finishing kernel sums the slabs and applies the epilogue (deterministic,

@@ -81,7 +81,8 @@ class NativeBackend:
         if cfg.sync == SYNC_DDP:
             C = native.lib()
             sizes = [s.numel * 4 for s in self.slots]
-            buckets = C.plan_buckets(sizes, int(cfg.bucket_cap_mb * (1 << 20)), 1 << 20)
+            buckets = C.plan_buckets(sizes, int(cfg.bucket_cap_mb * (1 << 20)),
+                                     int(cfg.first_bucket_cap_mb * (1 << 20)))
             slices = []
             for lo, hi in buckets:
                 start = self.slots[lo].offset
@@ -91,6 +92,12 @@ class NativeBackend:
             self.reducer = C.BucketReducer(comm.native, self.grads.data_ptr(), slices,
                                            reduce == "mean", cfg.serialize_streams)
             self.engine.set_reducer(self.reducer, buckets)
+            if cfg.batch_norm and cfg.broadcast_buffers:
+                # DDP's per-forward buffer broadcast, issued by the reducer after each
+                # forward (hidden under backward) and applied before the next one
+                self._bn_shadow = torch.zeros_like(self.bn_buffers)
+                self.reducer.set_buffer_sync(self.bn_buffers.data_ptr(),
+                                             self._bn_shadow.data_ptr(), self.engine.bn_elems)
             # what DistributedDataParallel's constructor does: everyone adopts rank 0's state
             if self.world > 1:
                 comm.broadcast(self.params, 0)
@@ -125,9 +132,6 @@ class NativeBackend:
         s = self._stream()
         if cfg.use_graph and self.world == 1:
             return self._train_step_graph(data, target, n, s)
-        if self.reducer is not None and cfg.batch_norm and cfg.broadcast_buffers \
-                and self.world > 1:
-            self.comm.broadcast(self.bn_buffers, 0)     # DDP's per-forward buffer broadcast
         e.forward_backward(data.data_ptr(), target.data_ptr(), n, s)
         self.sync.finish()
         e.optimizer_step(cfg.lr, cfg.momentum, cfg.weight_decay, 1.0, s)
@@ -217,6 +221,8 @@ class NativeBackend:
                 sd[b.name].to(device=self.device, dtype=torch.float32))
             steps = int(sd[b.name.rsplit(".", 1)[0] + ".num_batches_tracked"])
         self.engine.bn_steps = steps
+        if getattr(self, "reducer", None) is not None:
+            self.reducer.drop_pending_buffers()
         self.momentum.zero_()
         self.engine.refresh_weights(self._stream())
 

@@ -32,7 +32,8 @@ def build_sync(cfg: TrainConfig, comm: Optional[Communicator], flat: FlatModule)
         return AllReduceSync(comm, flat.grad_views(), reduce)
     if cfg.sync == SYNC_DDP:
         ints = [b for _, b in flat.module.named_buffers() if not b.dtype.is_floating_point]
-        return BucketedSync(comm, flat, reduce, cfg.bucket_cap_mb, cfg.broadcast_buffers, ints)
+        return BucketedSync(comm, flat, reduce, cfg.bucket_cap_mb, cfg.broadcast_buffers, ints,
+                            cfg.first_bucket_cap_mb)
     raise ValueError(cfg.sync)
 
 

@@ -124,13 +124,15 @@ class BucketedSync(GradSync):
 
     def __init__(self, comm: Communicator, flat: FlatModule, reduce: str = "mean",
                  bucket_cap_mb: float = 25.0, broadcast_buffers: bool = True,
-                 int_buffers: Optional[List[torch.Tensor]] = None):
+                 int_buffers: Optional[List[torch.Tensor]] = None,
+                 first_bucket_cap_mb: float = 1.0):
         super().__init__(comm, reduce)
         self.flat = flat
         self.broadcast_buffers = broadcast_buffers and comm.world_size > 1
         self.int_buffers = int_buffers or []
         sizes = [s.numel * 4 for s in flat.slots]
-        self.buckets = plan_buckets(sizes, int(bucket_cap_mb * (1 << 20)))
+        self.buckets = plan_buckets(sizes, int(bucket_cap_mb * (1 << 20)),
+                                    int(first_bucket_cap_mb * (1 << 20)))
         self._bucket_of = {}
         self._slices = []
         for b, (lo, hi) in enumerate(self.buckets):

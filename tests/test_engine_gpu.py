@@ -250,6 +250,35 @@ def test_sync_modes_world1_match_no_sync(sync):
         comm.destroy()
 
 
+def test_ddp_overlap_matches_serialized_streams():
+    """Race check for the side-stream choreography (bucket events, overlapped running-stat
+    broadcast, optimizer wait): the overlapped run must reproduce the debug mode that issues
+    every collective in line on the compute stream."""
+    from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
+    comm = RcclCommunicator("127.0.0.1:29611", 0, 1, 0, timeout_s=60)
+    try:
+        fast, _ = _mk(True, sync="ddp", comm=comm, bucket_cap_mb=1.0)
+        slow, _ = _mk(True, sync="ddp", comm=comm, bucket_cap_mb=1.0, serialize_streams=True)
+        base, _ = _mk(True)
+        assert fast.reducer.num_buckets >= 6
+        for step in range(4):
+            _, x4, t = _batch(32, seed=step)
+            la = float(fast.train_step(x4, t).item())
+            lb = float(slow.train_step(x4, t).item())
+            lc = float(base.train_step(x4, t).item())
+            # wgrad accumulates with float atomics: runs agree to (amplified) rounding
+            assert abs(la - lb) < 3e-2 and abs(la - lc) < 3e-2, (step, la, lb, lc)
+        comm.guard_sync(30)
+        assert _rel(fast.params, slow.params) < 1e-2
+        assert _rel(fast.params, base.params) < 1e-2
+        assert _rel(fast.bn_buffers, base.bn_buffers) < 1e-2
+        assert _rel(slow.bn_buffers, base.bn_buffers) < 1e-2
+        fast.close()
+        slow.close()
+    finally:
+        comm.destroy()
+
+
 def test_graph_replay_matches_eager():
     eager, _ = _mk(False)
     graph, _ = _mk(False, use_graph=True)
