@@ -53,9 +53,8 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
             continue;
         }
         if (w % 64) throw std::invalid_argument("VggEngine: channel widths must be multiples of 64");
-        if (convs_.empty() ? (w != 64) : (w % 128 != 0))
-            throw std::invalid_argument("VggEngine: first conv must have 64 channels, later ones a "
-                                        "multiple of 128");
+        if (convs_.empty() && w != 64)
+            throw std::invalid_argument("VggEngine: the first conv must have 64 channels");
         Conv c;
         c.cin = cin; c.cout = w; c.hw = hw; c.pool_after = false;
         c.gamma_off = c.beta_off = c.rm_off = c.rv_off = c.save_off = 0;

@@ -238,9 +238,9 @@ void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits) {
 void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
                    hipStream_t stream, int force_splits) {
     if (s.batch <= 0 || s.hw < 1 || s.hw > 32 || (s.hw & (s.hw - 1)) || s.cin % 64 ||
-        s.cout % 128 || s.cin < 64)
+        s.cout % 64 || s.cin < 64 || s.cout < 64)
         throw std::invalid_argument("conv3x3_wgrad: needs hw power of two <= 32, cin % 64 == 0, "
-                                    "cout % 128 == 0");
+                                    "cout % 64 == 0");
     WgradArgs a;
     a.x = x; a.dy = dy; a.dw = dw;
     a.M = s.batch * s.hw * s.hw; a.Cin = s.cin; a.Cout = s.cout;
@@ -250,8 +250,13 @@ void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s
         throw std::invalid_argument("conv3x3_wgrad: tensor exceeds 2^31 bytes");
     a.x_bytes = (unsigned)((size_t)a.M * s.cin * 2);
     a.dy_bytes = (unsigned)((size_t)a.M * s.cout * 2);
-    if (s.cin % 128 == 0) launch_wgrad<128, 128>(a, stream, force_splits);
-    else launch_wgrad<128, 64>(a, stream, force_splits);
+    if (s.cout % 128 == 0) {
+        if (s.cin % 128 == 0) launch_wgrad<128, 128>(a, stream, force_splits);
+        else launch_wgrad<128, 64>(a, stream, force_splits);
+    } else {        // 64-channel layers of the deeper VGG variants (64 -> 64 at 32x32)
+        if (s.cin % 128 == 0) launch_wgrad<64, 128>(a, stream, force_splits);
+        else launch_wgrad<64, 64>(a, stream, force_splits);
+    }
 }
 
 // ------------------------------------------------------------------ weight repacks

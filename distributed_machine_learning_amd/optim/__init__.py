@@ -1,1 +1,1 @@
-
+from .fused_sgd import FusedSGD  # noqa: F401

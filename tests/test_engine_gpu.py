@@ -12,14 +12,14 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
-def _mk(batch_norm, batch=32, sync="none", comm=None, **kw):
+def _mk(batch_norm, batch=32, sync="none", comm=None, arch="VGG11", **kw):
     from distributed_machine_learning_amd.config import TrainConfig
     from distributed_machine_learning_amd.engine.native_backend import NativeBackend
     from distributed_machine_learning_amd.models import VGG
     torch.manual_seed(1234)
-    ref = VGG("VGG11", batch_norm).to(DEV)
+    ref = VGG(arch, batch_norm).to(DEV)
     cfg = TrainConfig(batch_size=batch, batch_norm=batch_norm, sync=sync, dtype="bf16",
-                      backend="native", lr=0.01, **kw)
+                      backend="native", lr=0.01, arch=arch, **kw)
     nb = NativeBackend(cfg, DEV, comm, init_state=ref.state_dict())
     return nb, ref
 
@@ -197,6 +197,21 @@ def test_training_steps_track_torch(batch_norm):
         # only on weight tensors (biases start at zero, a relative error means little there)
         if p.dim() >= 2:
             assert _rel(sd[name], p) < 0.2, name
+
+
+@pytest.mark.parametrize("arch", ["VGG13", "VGG16", "VGG19"])
+def test_deeper_variants_first_step_matches_torch(arch):
+    """The reference's config table also holds VGG13/16/19 (/root/reference/part1/model.py:3-8,
+    `_VGG(name)` accepts any key): their 64 -> 64 layers and longer chains run on the same
+    kernels.  Loss and first-step parameter movement against the bf16-emulating torch model."""
+    nb, ref = _mk(True, batch=16, arch=arch)
+    x, x4, t = _batch(16, seed=3)
+    with torch.no_grad():
+        loss = F.cross_entropy(_emulated_forward(ref, x, True), t)
+    got = float(nb.train_step(x4, t).item())
+    assert abs(got - float(loss)) < 0.05 * max(1.0, abs(float(loss))), (got, float(loss))
+    assert len(nb.slots) == len(list(ref.parameters()))
+    assert bool(torch.isfinite(nb.params).all())
 
 
 def test_eval_and_checkpoint_roundtrip(tmp_path):

@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
 
-# (cin, cout, hw) of VGG-11 conv2..conv8 (conv1 has its own kernels)
+# (cin, cout, hw) of VGG-11 conv2..conv8 (conv1 has its own kernels), then the two extra
+# shapes the VGG13/16/19 tables need
 GENERIC_LAYERS = [(64, 128, 16), (128, 256, 8), (256, 256, 8), (256, 512, 4), (512, 512, 4),
-                  (512, 512, 2)]
+                  (512, 512, 2), (64, 64, 32), (128, 128, 16)]
 
 
 def native():
