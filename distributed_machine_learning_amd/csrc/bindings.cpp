@@ -110,6 +110,31 @@ PYBIND11_MODULE(_C, m) {
                     ptr<const float>(srstd), ptr<float>(dgamma), ptr<float>(dbeta), ptr<float>(ws),
                     rows, c, st(s));
     });
+    m.def("bn_relu_pool_fwd_train", [](uintptr_t x, uintptr_t y, uintptr_t gamma, uintptr_t beta,
+                                       uintptr_t rmean, uintptr_t rvar, uintptr_t smean,
+                                       uintptr_t srstd, uintptr_t ws, int batch, int hw, int c,
+                                       float momentum, float eps, uintptr_t s) {
+        bn_relu_pool_fwd_train(ptr<const bf16_raw>(x), ptr<bf16_raw>(y), ptr<const float>(gamma),
+                               ptr<const float>(beta), ptr<float>(rmean), ptr<float>(rvar),
+                               ptr<float>(smean), ptr<float>(srstd), ptr<float>(ws), batch, hw, c,
+                               momentum, eps, st(s));
+    });
+    m.def("bn_relu_pool_fwd_eval", [](uintptr_t x, uintptr_t y, uintptr_t gamma, uintptr_t beta,
+                                      uintptr_t rmean, uintptr_t rvar, int batch, int hw, int c,
+                                      float eps, uintptr_t s) {
+        bn_relu_pool_fwd_eval(ptr<const bf16_raw>(x), ptr<bf16_raw>(y), ptr<const float>(gamma),
+                              ptr<const float>(beta), ptr<const float>(rmean),
+                              ptr<const float>(rvar), batch, hw, c, eps, st(s));
+    });
+    m.def("bn_relu_pool_bwd", [](uintptr_t x, uintptr_t dy, uintptr_t dx, uintptr_t gamma,
+                                 uintptr_t beta, uintptr_t smean, uintptr_t srstd, uintptr_t dgamma,
+                                 uintptr_t dbeta, uintptr_t ws, int batch, int hw, int c,
+                                 uintptr_t s) {
+        bn_relu_pool_bwd(ptr<const bf16_raw>(x), ptr<const bf16_raw>(dy), ptr<bf16_raw>(dx),
+                         ptr<const float>(gamma), ptr<const float>(beta), ptr<const float>(smean),
+                         ptr<const float>(srstd), ptr<float>(dgamma), ptr<float>(dbeta),
+                         ptr<float>(ws), batch, hw, c, st(s));
+    });
     m.def("linear_fwd", [](uintptr_t x, uintptr_t w, uintptr_t b, uintptr_t logits, int batch,
                            int in_f, int out_f, uintptr_t s) {
         linear_fwd(ptr<const bf16_raw>(x), ptr<const float>(w), ptr<const float>(b),

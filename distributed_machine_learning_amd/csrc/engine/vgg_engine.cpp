@@ -114,7 +114,9 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         if (i > 0) a = align_up(a + (size_t)c.cout * 9 * c.cin);
         c.pre_off = a;
         if (bn_) a = align_up(a + act);
-        c.out_off = a; a = align_up(a + act);
+        c.out_off = a;
+        // under BatchNorm a pooled layer never stores its full-resolution activation
+        if (!(bn_ && c.pool_after)) a = align_up(a + act);
         c.pool_off = a;
         if (c.pool_after) a = align_up(a + act / 4);
     }
@@ -232,6 +234,20 @@ void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t
             conv3x3_igemm(in, arena_ + shadow_off_ + c.w_off, dst, params_ + c.b_off, nullptr, slab,
                           slab_elems_, s, bn_ ? EPI_BIAS : EPI_BIAS_RELU, stream);
         }
+        if (bn_ && c.pool_after) {
+            // BatchNorm + ReLU + max-pool in one pass; only the pooled tensor is written
+            if (training)
+                bn_relu_pool_fwd_train(dst, arena_ + c.pool_off, params_ + c.gamma_off,
+                                       params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off,
+                                       ws_ + c.save_off, ws_ + c.save_off + c.cout,
+                                       ws_ + stats_off_, batch, c.hw, c.cout, 0.1f, 1e-5f, stream);
+            else
+                bn_relu_pool_fwd_eval(dst, arena_ + c.pool_off, params_ + c.gamma_off,
+                                      params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off,
+                                      batch, c.hw, c.cout, 1e-5f, stream);
+            in = arena_ + c.pool_off;
+            continue;
+        }
         if (bn_) {
             const int rows = batch * c.hw * c.hw;
             if (training)
@@ -269,17 +285,26 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     for (int i = nconv - 1; i >= 0; --i) {
         const Conv& c = convs_[i];
         const int rows = batch * c.hw * c.hw;
-        if (c.pool_after) {
-            maxpool2x2_bwd(arena_ + c.out_off, arena_ + gbuf_off_[cur], arena_ + gbuf_off_[cur ^ 1],
-                           batch, c.hw, c.cout, /*relu_mask=*/!bn_, stream);
+        if (bn_ && c.pool_after) {
+            bn_relu_pool_bwd(arena_ + c.pre_off, arena_ + gbuf_off_[cur], arena_ + gbuf_off_[cur ^ 1],
+                             params_ + c.gamma_off, params_ + c.beta_off, ws_ + c.save_off,
+                             ws_ + c.save_off + c.cout, grads_ + c.gamma_off, grads_ + c.beta_off,
+                             ws_ + stats_off_, batch, c.hw, c.cout, stream);
             cur ^= 1;
-        }
-        if (bn_) {
-            bn_relu_bwd(arena_ + c.pre_off, arena_ + gbuf_off_[cur], arena_ + gbuf_off_[cur ^ 1],
-                        params_ + c.gamma_off, params_ + c.beta_off, ws_ + c.save_off,
-                        ws_ + c.save_off + c.cout, grads_ + c.gamma_off, grads_ + c.beta_off,
-                        ws_ + stats_off_, rows, c.cout, stream);
-            cur ^= 1;
+        } else {
+            if (c.pool_after) {
+                maxpool2x2_bwd(arena_ + c.out_off, arena_ + gbuf_off_[cur],
+                               arena_ + gbuf_off_[cur ^ 1], batch, c.hw, c.cout,
+                               /*relu_mask=*/!bn_, stream);
+                cur ^= 1;
+            }
+            if (bn_) {
+                bn_relu_bwd(arena_ + c.pre_off, arena_ + gbuf_off_[cur], arena_ + gbuf_off_[cur ^ 1],
+                            params_ + c.gamma_off, params_ + c.beta_off, ws_ + c.save_off,
+                            ws_ + c.save_off + c.cout, grads_ + c.gamma_off, grads_ + c.beta_off,
+                            ws_ + stats_off_, rows, c.cout, stream);
+                cur ^= 1;
+            }
         }
         const uint16_t* g = arena_ + gbuf_off_[cur];       // dL/d(conv output), mask applied
         if (i == 0) {

@@ -75,17 +75,20 @@ __device__ __forceinline__ void column_partials(RowFn&& row_values, float* ws, i
     }
 }
 
-// Kernel-2 body: grid = ceil(c / 64) blocks of 256 threads = 64 columns x 4 row parts.
+// Kernel-2 body: grid = fold_blocks(c) blocks of 256 threads = 16 columns x 16 row parts (a
+// fold is latency-bound: many short dependent chains beat few long ones).
 // finalize(col, sum_a, sum_b) runs once per column.
+inline int fold_blocks(int c) { return (c + 15) / 16; }
+
 template <typename FinalFn>
 __device__ __forceinline__ void column_fold(FinalFn&& finalize, const float* ws, int nb, int c) {
-    __shared__ float fold[2][4][64];
-    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
+    __shared__ float fold[2][16][17];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
     float sa = 0.f, sb = 0.f;
     if (col < c) {
 #pragma unroll 4
-        for (int k = part; k < nb; k += 4) {
+        for (int k = part; k < nb; k += 16) {
             sa += ws[(size_t)k * 2 * c + col];
             sb += ws[(size_t)k * 2 * c + c + col];
         }
@@ -93,9 +96,12 @@ __device__ __forceinline__ void column_fold(FinalFn&& finalize, const float* ws,
     fold[0][part][cl] = sa;
     fold[1][part][cl] = sb;
     __syncthreads();
-    if (part == 0 && col < c)
-        finalize(col, fold[0][0][cl] + fold[0][1][cl] + fold[0][2][cl] + fold[0][3][cl],
-                 fold[1][0][cl] + fold[1][1][cl] + fold[1][2][cl] + fold[1][3][cl]);
+    if (part == 0 && col < c) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { ta += fold[0][q][cl]; tb += fold[1][q][cl]; }
+        finalize(col, ta, tb);
+    }
 }
 
 }  // namespace dml

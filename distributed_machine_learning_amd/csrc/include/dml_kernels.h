@@ -106,6 +106,22 @@ void bn_relu_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const floa
                  float* dgamma, float* dbeta, float* stats_ws, int rows, int c,
                  hipStream_t stream);
 
+// BatchNorm + ReLU + 2x2/2 max-pool in one pass each way (x is the conv output
+// [batch][hw][hw][c], y / dy the pooled tensor [batch][hw/2][hw/2][c]).  The full-resolution
+// activation and its gradient are never materialised: backward recomputes the winning
+// window position from x.
+void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* save_mean,
+                            float* save_rstd, float* ws, int batch, int hw, int c, float momentum,
+                            float eps, hipStream_t stream);
+void bn_relu_pool_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
+                           const float* running_mean, const float* running_var, int batch, int hw,
+                           int c, float eps, hipStream_t stream);
+void bn_relu_pool_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+                      const float* beta, const float* save_mean, const float* save_rstd,
+                      float* dgamma, float* dbeta, float* ws, int batch, int hw, int c,
+                      hipStream_t stream);
+
 // ---------------------------------------------------------------- classifier + loss
 // logits[b][n] = sum_k x[b][k] * w[n][k] + bias[n]      (x bf16, w/bias/logits fp32, n <= 16)
 void linear_fwd(const bf16_raw* x, const float* w, const float* bias, float* logits, int batch,

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
         float v[8], o[8];
         unpack8(*(const uint4*)(x + i * 8), v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
+        for (int k = 0; k < 8; ++k) o[k] = fmaxf(__builtin_fmaf(v[k], sc[k], sh[k]), 0.f);
         *(uint4*)(y + i * 8) = pack8(o);
     }
 }
@@ -119,7 +119,7 @@ void bn_relu_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const
     const ColReducePlan pl = plan_col_reduce(rows, c);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, c,
                        pl.rows_per_block);
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((c + 63) / 64), dim3(256), 0, stream,
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
                        (const float*)ws, save_mean, save_rstd, running_mean, running_var, pl.blocks,
                        rows, c, momentum, eps);
     const size_t total8 = (size_t)rows * (c / 8);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             unpack8(*(const uint4*)(dy + (size_t)r * c + cg * 8), g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float gi = (v[i] * ysc[i] + ysh[i] > 0.f) ? g[i] : 0.f;
+                const float gi = (__builtin_fmaf(v[i], ysc[i], ysh[i]) > 0.f) ? g[i] : 0.f;
                 a[i] += gi;
                 b[i] += gi * (v[i] * rs[i] - mrs[i]);
             }
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         unpack8(*(const uint4*)(dy + i * 8), g);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float gi = (v[k] * ysc[k] + ysh[k] > 0.f) ? g[k] : 0.f;
+            const float gi = (__builtin_fmaf(v[k], ysc[k], ysh[k]) > 0.f) ? g[k] : 0.f;
             o[k] = k1[k] * gi - k2[k] - k3[k] * v[k];
         }
         *(uint4*)(dx + i * 8) = pack8(o);
@@ -234,12 +234,240 @@ void bn_relu_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const floa
     const ColReducePlan pl = plan_col_reduce(rows, c);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, dy, gamma,
                        beta, save_mean, save_rstd, ws, rows, c, pl.rows_per_block);
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((c + 63) / 64), dim3(256), 0, stream,
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
                        (const float*)ws, dgamma, dbeta, pl.blocks, c);
     const size_t total8 = (size_t)rows * (c / 8);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(total8)), dim3(256), 0, stream, x, dy,
                        dx, gamma, beta, save_mean, save_rstd, (const float*)dgamma,
                        (const float*)dbeta, rows, c, total8);
+}
+
+
+// ------------------------------------------------ BatchNorm + ReLU + 2x2 max-pool fused
+// When a 2x2/2 max-pool follows (nn.MaxPool2d(kernel_size=2, stride=2),
+// /root/reference/part1/model.py:16) the full-resolution activation is never stored:
+// forward reads the four window positions of the conv output, applies scale/shift/ReLU and
+// writes only the pooled maximum; backward re-derives the winning position (first maximum
+// in row-major window order, strict comparisons, the same fma as forward) from the conv
+// output, so neither the activation nor its full-resolution gradient ever touch memory.
+struct PoolGeom {
+    int c8, log_oh, hw;      // c / 8, log2(output side), input side
+    __device__ __forceinline__ size_t in_pixel(size_t opix) const {
+        const int oh = 1 << log_oh;
+        const size_t ow_ = opix & (oh - 1);
+        const size_t oh_ = (opix >> log_oh) & (oh - 1);
+        const size_t b = opix >> (2 * log_oh);
+        return (b * hw + 2 * oh_) * hw + 2 * ow_;
+    }
+};
+
+__device__ __forceinline__ void load_window(const uint16_t* __restrict__ x, size_t ipix, int cg,
+                                            int c, int hw, float (&v)[4][8]) {
+    const uint16_t* p = x + ipix * c + cg * 8;
+    const uint4 q0 = *(const uint4*)(p);
+    const uint4 q1 = *(const uint4*)(p + c);
+    const uint4 q2 = *(const uint4*)(p + (size_t)hw * c);
+    const uint4 q3 = *(const uint4*)(p + (size_t)hw * c + c);
+    unpack8(q0, v[0]); unpack8(q1, v[1]); unpack8(q2, v[2]); unpack8(q3, v[3]);
+}
+
+__device__ __forceinline__ void load_consts(const float* __restrict__ p, int col, float (&o)[8]) {
+    const float4 a = *(const float4*)(p + col), b = *(const float4*)(p + col + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
+template <bool FROM_VAR>
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(
+    const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ rstd_or_var, int c, float eps, PoolGeom geo, size_t total8) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int cg = (int)(i % geo.c8);
+    float sc[8], sh[8];
+    {
+        float g[8], bb[8], m[8], rr[8];
+        load_consts(gamma, cg * 8, g); load_consts(beta, cg * 8, bb);
+        load_consts(mean, cg * 8, m); load_consts(rstd_or_var, cg * 8, rr);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float rs = FROM_VAR ? rsqrtf(rr[k] + eps) : rr[k];
+            sc[k] = g[k] * rs;
+            sh[k] = bb[k] - m[k] * sc[k];
+        }
+    }
+    for (; i < total8; i += stride) {
+        float v[4][8], o[8];
+        load_window(x, geo.in_pixel(i / geo.c8), cg, c, geo.hw, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float z0 = __builtin_fmaf(v[0][k], sc[k], sh[k]);
+            const float z1 = __builtin_fmaf(v[1][k], sc[k], sh[k]);
+            const float z2 = __builtin_fmaf(v[2][k], sc[k], sh[k]);
+            const float z3 = __builtin_fmaf(v[3][k], sc[k], sh[k]);
+            o[k] = fmaxf(fmaxf(fmaxf(z0, z1), fmaxf(z2, z3)), 0.f);
+        }
+        *(uint4*)(y + i * 8) = pack8(o);
+    }
+}
+
+// Winner of the window for one channel: index of the first maximum of z, and whether the
+// pooled activation was positive (otherwise ReLU blocks the gradient).
+__device__ __forceinline__ int window_winner(float z0, float z1, float z2, float z3, bool& live) {
+    int w = 0;
+    float m = z0;
+    if (z1 > m) { m = z1; w = 1; }
+    if (z2 > m) { m = z2; w = 2; }
+    if (z3 > m) { m = z3; w = 3; }
+    live = m > 0.f;
+    return w;
+}
+
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ ws,
+    int out_rows, int c, int rows_per_block, PoolGeom geo) {
+    __shared__ float red[4096];
+    float rs[8], mrs[8], ysc[8], ysh[8];
+    {
+        const int col0 = (threadIdx.x % (c / 8)) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            rs[i] = rstd[col0 + i];
+            mrs[i] = mean[col0 + i] * rs[i];
+            ysc[i] = gamma[col0 + i] * rs[i];
+            ysh[i] = beta[col0 + i] - gamma[col0 + i] * mrs[i];
+        }
+    }
+    column_partials(
+        [&](int r, int cg, float (&a)[8], float (&b)[8]) {
+            float v[4][8], g[8];
+            load_window(x, geo.in_pixel((size_t)r), cg, c, geo.hw, v);
+            unpack8(*(const uint4*)(dy + (size_t)r * c + cg * 8), g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bool live;
+                const int w = window_winner(__builtin_fmaf(v[0][i], ysc[i], ysh[i]),
+                                            __builtin_fmaf(v[1][i], ysc[i], ysh[i]),
+                                            __builtin_fmaf(v[2][i], ysc[i], ysh[i]),
+                                            __builtin_fmaf(v[3][i], ysc[i], ysh[i]), live);
+                const float xv = w == 0 ? v[0][i] : w == 1 ? v[1][i] : w == 2 ? v[2][i] : v[3][i];
+                const float gi = live ? g[i] : 0.f;
+                a[i] += gi;
+                b[i] += gi * (xv * rs[i] - mrs[i]);
+            }
+        },
+        ws, out_rows, c, rows_per_block, red);
+}
+
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ dgamma, const float* __restrict__ dbeta, int in_rows, int c,
+    PoolGeom geo, size_t total8) {
+    const float inv_n = 1.f / (float)in_rows;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int cg = (int)(i % geo.c8);
+    float ysc[8], ysh[8], k1[8], k2[8], k3[8];
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int col = cg * 8 + k;
+            const float rs = rstd[col];
+            const float mrs = mean[col] * rs;
+            ysc[k] = gamma[col] * rs;
+            ysh[k] = beta[col] - gamma[col] * mrs;
+            k1[k] = gamma[col] * rs;
+            const float dg = dgamma[col] * inv_n, db = dbeta[col] * inv_n;
+            k2[k] = k1[k] * (db - mrs * dg);
+            k3[k] = k1[k] * rs * dg;
+        }
+    }
+    for (; i < total8; i += stride) {
+        float v[4][8], g[8], o[4][8];
+        const size_t ipix = geo.in_pixel(i / geo.c8);
+        load_window(x, ipix, cg, c, geo.hw, v);
+        unpack8(*(const uint4*)(dy + i * 8), g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bool live;
+            const int w = window_winner(__builtin_fmaf(v[0][k], ysc[k], ysh[k]),
+                                        __builtin_fmaf(v[1][k], ysc[k], ysh[k]),
+                                        __builtin_fmaf(v[2][k], ysc[k], ysh[k]),
+                                        __builtin_fmaf(v[3][k], ysc[k], ysh[k]), live);
+            const float gk = live ? k1[k] * g[k] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                o[q][k] = (w == q ? gk : 0.f) - k2[k] - k3[k] * v[q][k];
+        }
+        uint16_t* p = dx + ipix * c + cg * 8;
+        *(uint4*)(p) = pack8(o[0]);
+        *(uint4*)(p + c) = pack8(o[1]);
+        *(uint4*)(p + (size_t)geo.hw * c) = pack8(o[2]);
+        *(uint4*)(p + (size_t)geo.hw * c + c) = pack8(o[3]);
+    }
+}
+
+namespace {
+PoolGeom pool_geom(int batch, int hw, int c, const char* who) {
+    if (batch <= 0 || hw < 2 || hw > 64 || (hw & (hw - 1)))
+        throw std::invalid_argument(std::string(who) + ": hw must be a power of two in [2, 64]");
+    int l = 0;
+    while ((1 << l) < hw / 2) ++l;
+    return {c / 8, l, hw};
+}
+}  // namespace
+
+void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* save_mean,
+                            float* save_rstd, float* ws, int batch, int hw, int c, float momentum,
+                            float eps, hipStream_t stream) {
+    const int rows = batch * hw * hw;
+    check(rows, c, "bn_relu_pool_fwd_train");
+    const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_fwd_train");
+    const ColReducePlan pl = plan_col_reduce(rows, c);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, c,
+                       pl.rows_per_block);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
+                       (const float*)ws, save_mean, save_rstd, running_mean, running_var, pl.blocks,
+                       rows, c, momentum, eps);
+    const size_t total8 = (size_t)(rows / 4) * (c / 8);
+    hipLaunchKernelGGL(bn_apply_pool_kernel<false>, dim3(apply_blocks(total8)), dim3(256), 0,
+                       stream, x, y, gamma, beta, (const float*)save_mean,
+                       (const float*)save_rstd, c, eps, geo, total8);
+}
+
+void bn_relu_pool_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
+                           const float* running_mean, const float* running_var, int batch, int hw,
+                           int c, float eps, hipStream_t stream) {
+    const int rows = batch * hw * hw;
+    check(rows, c, "bn_relu_pool_fwd_eval");
+    const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_fwd_eval");
+    const size_t total8 = (size_t)(rows / 4) * (c / 8);
+    hipLaunchKernelGGL(bn_apply_pool_kernel<true>, dim3(apply_blocks(total8)), dim3(256), 0, stream,
+                       x, y, gamma, beta, running_mean, running_var, c, eps, geo, total8);
+}
+
+void bn_relu_pool_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+                      const float* beta, const float* save_mean, const float* save_rstd,
+                      float* dgamma, float* dbeta, float* ws, int batch, int hw, int c,
+                      hipStream_t stream) {
+    const int rows = batch * hw * hw;
+    check(rows, c, "bn_relu_pool_bwd");
+    const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_bwd");
+    const int out_rows = rows / 4;
+    const ColReducePlan pl = plan_col_reduce(out_rows, c);
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, dy,
+                       gamma, beta, save_mean, save_rstd, ws, out_rows, c, pl.rows_per_block, geo);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
+                       (const float*)ws, dgamma, dbeta, pl.blocks, c);
+    const size_t total8 = (size_t)out_rows * (c / 8);
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(apply_blocks(total8)), dim3(256), 0, stream,
+                       x, dy, dx, gamma, beta, save_mean, save_rstd, (const float*)dgamma,
+                       (const float*)dbeta, rows, c, geo, total8);
 }
 
 }  // namespace dml

@@ -129,7 +129,7 @@ void column_sum(const bf16_raw* x, float* out, int rows, int cols, float* ws, hi
     const ColReducePlan pl = plan_col_reduce(rows, cols);
     hipLaunchKernelGGL(column_sum_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, cols,
                        pl.rows_per_block);
-    hipLaunchKernelGGL(column_sum_finish_kernel, dim3((cols + 63) / 64), dim3(256), 0, stream,
+    hipLaunchKernelGGL(column_sum_finish_kernel, dim3(fold_blocks(cols)), dim3(256), 0, stream,
                        (const float*)ws, out, pl.blocks, cols);
 }
 

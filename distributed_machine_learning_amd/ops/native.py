@@ -190,8 +190,8 @@ _REDUCE_WS = {}
 
 
 def _reduce_ws(device) -> torch.Tensor:
-    """Scratch of the in-launch column reductions (zero before first use; every launch
-    leaves its ticket counter at zero again).  One per device and stream-ordered use."""
+    """Partial-sum slab of the two-kernel column reductions.  One per device; launches that
+    share it must be ordered on one stream."""
     key = (device.type, device.index)
     if key not in _REDUCE_WS:
         _REDUCE_WS[key] = torch.zeros(lib().column_reduce_workspace_elems(), dtype=torch.float32,
@@ -262,6 +262,51 @@ def bn_relu_bwd(x, dy, gamma, beta, save_mean, save_rstd):
     lib().bn_relu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                       save_mean.data_ptr(), save_rstd.data_ptr(), dgamma.data_ptr(),
                       dbeta.data_ptr(), ws.data_ptr(), x.numel() // c, c, _stream())
+    return dx, dgamma, dbeta
+
+
+def bn_relu_pool_fwd_train(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1,
+                           eps=1e-5):
+    """BatchNorm + ReLU + 2x2 max-pool; returns ``(pooled, save_mean, save_rstd)``."""
+    _req(x, torch.bfloat16, "x", 4)
+    b, h, w, c = x.shape
+    if h != w or h % 2:
+        raise ValueError("bn_relu_pool: square even inputs only")
+    y = torch.empty(b, h // 2, w // 2, c, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    lib().bn_relu_pool_fwd_train(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                 _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
+                                 rstd.data_ptr(), _reduce_ws(x.device).data_ptr(), b, h, c,
+                                 momentum, eps, _stream())
+    return y, mean, rstd
+
+
+def bn_relu_pool_fwd_eval(x, gamma, beta, running_mean, running_var, eps=1e-5):
+    _req(x, torch.bfloat16, "x", 4)
+    b, h, w, c = x.shape
+    y = torch.empty(b, h // 2, w // 2, c, dtype=torch.bfloat16, device=x.device)
+    lib().bn_relu_pool_fwd_eval(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                running_mean.data_ptr(), running_var.data_ptr(), b, h, c, eps,
+                                _stream())
+    return y
+
+
+def bn_relu_pool_bwd(x, dy, gamma, beta, save_mean, save_rstd):
+    """``x`` the conv output, ``dy`` the gradient of the pooled tensor; returns
+    ``(dx, dgamma, dbeta)``."""
+    _req(x, torch.bfloat16, "x", 4)
+    _req(dy, torch.bfloat16, "dy", 4)
+    b, h, w, c = x.shape
+    if tuple(dy.shape) != (b, h // 2, w // 2, c):
+        raise ValueError("bn_relu_pool_bwd: shape mismatch")
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    lib().bn_relu_pool_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(),
+                           beta.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
+                           dgamma.data_ptr(), dbeta.data_ptr(), _reduce_ws(x.device).data_ptr(),
+                           b, h, c, _stream())
     return dx, dgamma, dbeta
 
 

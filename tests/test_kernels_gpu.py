@@ -186,6 +186,35 @@ def test_bn_relu(c, rows_shape):
     check("bn eval", nchw(ye), refe)
 
 
+@pytest.mark.parametrize("c,shape", [(64, (4, 32, 32)), (256, (16, 8, 8)), (512, (64, 2, 2))])
+def test_bn_relu_pool_fused(c, shape):
+    """BatchNorm + ReLU + 2x2 max-pool in one pass each way against the three torch ops."""
+    n = native()
+    b, hw, _ = shape
+    x = (rand_bf16(b, hw, hw, c, scale=2.0, seed=26) + 0.5).to(torch.bfloat16)
+    gamma = torch.rand(c, device=DEV) + 0.5
+    beta = torch.randn(c, device=DEV) * 0.2
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    xr = nchw(x).requires_grad_(True)
+    g_ref = gamma.clone().requires_grad_(True)
+    b_ref = beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.max_pool2d(F.relu(F.batch_norm(xr, rm_ref, rv_ref, g_ref, b_ref, True, 0.1, 1e-5)), 2)
+    y, mean, rstd = n.bn_relu_pool_fwd_train(x, gamma, beta, rm, rv)
+    check("bn+pool fwd", nchw(y), ref.detach())
+    check("bn+pool running_mean", rm, rm_ref, rtol=1e-4, atol_scale=1e-4)
+    check("bn+pool running_var", rv, rv_ref, rtol=1e-3, atol_scale=1e-3)
+    dy = rand_bf16(b, hw // 2, hw // 2, c, seed=27)
+    ref.backward(nchw(dy))
+    dx, dgamma, dbeta = n.bn_relu_pool_bwd(x, dy, gamma, beta, mean, rstd)
+    check("bn+pool dgamma", dgamma, g_ref.grad, rtol=5e-3, atol_scale=5e-3)
+    check("bn+pool dbeta", dbeta, b_ref.grad, rtol=5e-3, atol_scale=5e-3)
+    check("bn+pool dx", nchw(dx), xr.grad, rtol=2e-2, atol_scale=2e-2)
+    ye = n.bn_relu_pool_fwd_eval(x, gamma, beta, rm, rv)
+    refe = F.max_pool2d(F.relu(F.batch_norm(nchw(x), rm, rv, gamma, beta, False, 0.1, 1e-5)), 2)
+    check("bn+pool eval", nchw(ye), refe)
+
+
 @pytest.mark.parametrize("batch", [3, 256])
 def test_linear_and_softmax_xent(batch):
     n = native()
