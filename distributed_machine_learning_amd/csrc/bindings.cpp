@@ -38,8 +38,9 @@ PYBIND11_MODULE(_C, m) {
     // ------------------------------------------------------------------ kernels
     m.def("conv3x3_igemm", [](uintptr_t x, uintptr_t w, uintptr_t y, uintptr_t bias, uintptr_t mask,
                               uintptr_t ws, size_t ws_elems, int batch, int hw, int cin, int cout,
-                              int epi, uintptr_t stream, int bm, int bn, int splits) {
-        const int force[3] = {bm, bn, splits};
+                              int epi, uintptr_t stream, int bm, int bn, int splits, int pm,
+                              int waves) {
+        const int force[5] = {bm, bn, splits, pm, waves};
         conv3x3_igemm(ptr<const bf16_raw>(x), ptr<const bf16_raw>(w), ptr<bf16_raw>(y),
                       ptr<const float>(bias), ptr<const bf16_raw>(mask), ptr<float>(ws), ws_elems,
                       shape(batch, hw, cin, cout), (ConvEpilogue)epi, st(stream),
@@ -47,7 +48,7 @@ PYBIND11_MODULE(_C, m) {
     }, py::arg("x"), py::arg("w"), py::arg("y"), py::arg("bias"), py::arg("mask"), py::arg("ws"),
        py::arg("ws_elems"), py::arg("batch"), py::arg("hw"), py::arg("cin"), py::arg("cout"),
        py::arg("epi"), py::arg("stream"), py::arg("bm") = 0, py::arg("bn") = 0,
-       py::arg("splits") = 0);
+       py::arg("splits") = 0, py::arg("pm") = -1, py::arg("waves") = 4);
     m.def("conv3x3_igemm_workspace_elems", [](int batch, int hw, int cin, int cout) {
         return conv3x3_igemm_workspace_elems(shape(batch, hw, cin, cout));
     });

@@ -42,7 +42,7 @@ struct ConvShape {
 void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
                    const bf16_raw* mask, float* workspace, size_t workspace_elems,
                    ConvShape s, ConvEpilogue epi, hipStream_t stream,
-                   const int* force_plan = nullptr /* {BM, BN, splits} for tuning */);
+                   const int* force_plan = nullptr /* tuning: {BM, BN, splits, position-major (-1 auto), waves} */);
 size_t conv3x3_igemm_workspace_elems(ConvShape s);
 
 // First layer: x is [B,32,32,4] bf16 (3 channels + zero pad), w1 is [64][64] bf16 with

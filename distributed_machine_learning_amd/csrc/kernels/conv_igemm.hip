@@ -57,6 +57,7 @@ struct IgemmArgs {
     int log_chunks;       // log2(C / 64)
     int tiles_n;
     int taps_per_split;
+    int batch, img_blocks;   // position-major tiling: images, and tiles per spatial position
     unsigned x_bytes;     // extents for the buffer descriptors (out-of-range loads return 0)
     unsigned w_bytes;
 };
@@ -92,12 +93,30 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
-template <int BM, int BN, int WAVES_M, int EPI, bool SPLIT, int NS>
-__global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
-    constexpr int WAVES_N = 4 / WAVES_M;
+// cache-policy bits of the weight loads (0 = default; marking them non-temporal to keep
+// the pixel lines in L1 measured 1-5 % slower)
+#ifndef DML_W_AUX
+#define DML_W_AUX 0
+#endif
+
+// PM ("position-major") tiling: the BM rows of a tile are BM consecutive IMAGES at ONE
+// spatial position instead of BM consecutive NHWC pixels.  Whether a tap falls into the
+// padding then is the same for every row of the tile, so padded taps are skipped as whole K
+// steps (56 % of the work at 2x2, 31 % at 4x4, 16 % at 8x8) instead of multiplying zeros.
+// Rows are 128-byte K chunks fetched by per-lane addresses either way, so the memory layout
+// stays NHWC.
+//
+// NW = waves per block (4 or 8).  Eight waves put two waves on every SIMD of the CU a large
+// tile occupies alone, so one wave's waits (LDS fragments, the stage barrier) hide behind the
+// other's MFMAs without shrinking the tile (the L2 -> LDS feed rate, ~28 B/clk/CU, is what
+// bounds small tiles: bytes per flop fall with tile size).
+template <int BM, int BN, int WAVES_M, int EPI, bool SPLIT, int NS, bool PM, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
+    constexpr int WAVES_N = NW / WAVES_M;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;     // 1 KiB wave-loads per step and wave
+    constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW);   // 1 KiB wave-loads per step and wave
+    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for this many waves");
     constexpr int LPS = A_IT + B_IT;                  // loads per step per wave
     constexpr int D = NS - 1;                         // prefetch distance in K steps
     constexpr int STAGE_BYTES = (BM + BN) * 128;
@@ -113,12 +132,28 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
 
     const int tile_n = blockIdx.x % p.tiles_n;
     const int tile_m = blockIdx.x / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int n0 = tile_n * BN;
+    const int C = p.C, hw = p.hw;
+    // NHWC tiling: rows m0.. are consecutive pixels.  PM tiling: row r is image img0 + r at
+    // position pos (tiles of neighbouring positions are adjacent in the grid, they share
+    // input lines in L2).
+    const int P = hw * hw;
+    const int pos = PM ? tile_m % P : 0;
+    const int img0 = PM ? (tile_m / P) * BM : 0;
+    const int m0 = PM ? 0 : tile_m * BM;
     const int tap_begin = SPLIT ? blockIdx.y * p.taps_per_split : 0;
     const int tap_end = SPLIT ? min(9, tap_begin + p.taps_per_split) : 9;
-    const int ntaps = tap_end - tap_begin;
-
-    const int C = p.C, hw = p.hw;
+    // taps this block multiplies, 4 bits each (PM: only those inside the image)
+    unsigned long long tap_list = 0;
+    int ntaps = 0;
+    for (int t = tap_begin; t < tap_end; ++t) {
+        bool valid = true;
+        if (PM) {
+            const int hh = (pos >> p.log_hw) + t / 3 - 1, ww = (pos & (hw - 1)) + t % 3 - 1;
+            valid = (unsigned)hh < (unsigned)hw && (unsigned)ww < (unsigned)hw;
+        }
+        if (valid) tap_list |= (unsigned long long)t << (4 * ntaps++);
+    }
     const int steps = ntaps << p.log_chunks;
 
     // ---- staging.  Wave w streams rows [w*BM/4, (w+1)*BM/4) of the pixel tile and the same
@@ -132,17 +167,18 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
     int pix_hw[A_IT];        // (h << 16) | w
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int r = wave * (BM / 4) + i * 8 + lrow;
-        const int m = m0 + r;
+        const int r = wave * (BM / NW) + i * 8 + lrow;
+        const int m = PM ? (img0 + r) * P + pos : m0 + r;
+        const bool row_ok = PM ? (img0 + r < p.batch) : (m < p.M);
         const int w_ = m & (hw - 1);
         const int h_ = (m >> p.log_hw) & (hw - 1);
         pix_hw[i] = (h_ << 16) | w_;
-        pix_off[i] = (m < p.M) ? m * C + ((slot ^ ((r >> 1) & 7)) << 3) : -1;
+        pix_off[i] = row_ok ? m * C + ((slot ^ ((r >> 1) & 7)) << 3) : -1;
     }
     int w_off[B_IT];         // byte offset of (n, tap 0, chunk) in the weight matrix
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int r = wave * (BN / 4) + i * 8 + lrow;
+        const int r = wave * (BN / NW) + i * 8 + lrow;
         w_off[i] = ((n0 + r) * 9 * C + ((slot ^ ((r >> 1) & 7)) << 3)) * 2;
     }
     const __amdgpu_buffer_rsrc_t xrsrc =
@@ -152,13 +188,15 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
 
     // K order: channel chunk outer, tap inner - nine consecutive steps re-read the same
     // 128-byte lines of neighbouring pixels, so all but the first come from L1/L2.
+    int issue_cc = 0, issue_ti = 0;      // issue() is called for s = 0, 1, 2, ... in order
     auto issue = [&](int s) {
-        const int cc = s / ntaps;
-        const int tap = tap_begin + (s - cc * ntaps);
+        const int cc = issue_cc;
+        const int tap = (int)((tap_list >> (4 * issue_ti)) & 15);
+        if (++issue_ti == ntaps) { issue_ti = 0; ++issue_cc; }
         const int dh = tap / 3 - 1, dw = tap % 3 - 1;
         const int shift = (dh * hw + dw) * C + cc * 64;
-        char* sA = smem + (s % NS) * STAGE_BYTES + wave * (BM / 4) * 128;
-        char* sB = smem + (s % NS) * STAGE_BYTES + BM * 128 + wave * (BN / 4) * 128;
+        char* sA = smem + (s % NS) * STAGE_BYTES + wave * (BM / NW) * 128;
+        char* sB = smem + (s % NS) * STAGE_BYTES + BM * 128 + wave * (BN / NW) * 128;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int hh = (pix_hw[i] >> 16) + dh, ww = (pix_hw[i] & 0xffff) + dw;
@@ -175,7 +213,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
             // template when an expression is passed in this argument position)
             const int voff = w_off[i] + wshift;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + i * 1024), 16, voff, 0,
-                                                     0, 0);
+                                                     0, DML_W_AUX);
         }
     };
 
@@ -234,8 +272,9 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
     // ---- epilogue: D[n][m]; lane holds n = nb + 4*lq + {0..3}, m = mb + l15
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * WTM + j * 16 + l15;
-        if (m >= p.M) continue;
+        const int row = wm * WTM + j * 16 + l15;
+        const int m = PM ? (img0 + row) * P + pos : m0 + row;
+        if (PM ? (img0 + row >= p.batch) : (m >= p.M)) continue;
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int n = n0 + wn * WTN + i * 16 + lq * 4;
@@ -255,15 +294,27 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(IgemmArgs p) {
 }
 
 // Explicit instantiations of every (tile, epilogue) variant the launcher can pick.
-#define DML_IGEMM_INSTANTIATE(BM, BN, NS)                                                        \
-    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_NONE, true, NS>(IgemmArgs);     \
-    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_NONE, false, NS>(IgemmArgs);    \
-    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_BIAS, false, NS>(IgemmArgs);    \
-    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_BIAS_RELU, false, NS>(IgemmArgs); \
-    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_MASK, false, NS>(IgemmArgs);
-DML_IGEMM_INSTANTIATE(128, 128, 3)
-DML_IGEMM_INSTANTIATE(128, 64, 3)
-DML_IGEMM_INSTANTIATE(64, 64, 4)
+#define DML_IGEMM_INSTANTIATE(BM, BN, NS, PM, NW)                                                \
+    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_NONE, true, NS, PM, NW>(        \
+        IgemmArgs);                                                                              \
+    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_NONE, false, NS, PM, NW>(       \
+        IgemmArgs);                                                                              \
+    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_BIAS, false, NS, PM, NW>(       \
+        IgemmArgs);                                                                              \
+    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_BIAS_RELU, false, NS, PM, NW>(  \
+        IgemmArgs);                                                                              \
+    template __global__ void conv3x3_igemm_kernel<BM, BN, 2, EPI_MASK, false, NS, PM, NW>(       \
+        IgemmArgs);
+DML_IGEMM_INSTANTIATE(128, 128, 3, false, 4)
+DML_IGEMM_INSTANTIATE(128, 64, 3, false, 4)
+DML_IGEMM_INSTANTIATE(64, 64, 4, false, 4)
+DML_IGEMM_INSTANTIATE(128, 128, 3, true, 4)
+DML_IGEMM_INSTANTIATE(128, 64, 3, true, 4)
+DML_IGEMM_INSTANTIATE(64, 64, 4, true, 4)
+DML_IGEMM_INSTANTIATE(128, 128, 3, false, 8)
+DML_IGEMM_INSTANTIATE(128, 128, 4, false, 8)
+DML_IGEMM_INSTANTIATE(128, 128, 3, true, 8)
+DML_IGEMM_INSTANTIATE(128, 128, 4, true, 8)
 #undef DML_IGEMM_INSTANTIATE
 
 // Sums the per-split fp32 slabs and applies the epilogue; 4 outputs per thread.
@@ -297,53 +348,79 @@ int ilog2(int v) {
 
 struct Plan {
     int bm, bn, splits;
+    bool pm;
+    int waves;      // 4, 8 (3 LDS stages) or 9 = eight waves with 4 LDS stages (tuning)
 };
 
-// Tile / split choice, from per-layer timings on MI355X at batch 256 (tools/bench_conv.py):
-// with the LDS-DMA pipeline a K step is latency-bound per block, so the fastest plan is the
-// one that keeps >= 2 blocks per CU resident - 128x64 once that still gives >= 512 blocks,
-// else 64x64; layers that cannot reach one block per CU even at 64x64 split the taps.
-Plan choose_plan(int M, int N, const int* force = nullptr) {
-    if (force && force[0] > 0) return {force[0], force[1], force[2] > 0 ? force[2] : 1};
-    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (N / bn); };
-    if (blocks(128, 64) >= 512) return {128, 64, 1};
+// Tile / split choice, from per-layer timings on MI355X at batch 256 (tools/bench_conv.py).
+// The kernels are bound by the L2 -> LDS feed (~22-28 B/clk/CU), so bytes per flop decide:
+// the largest tile that still covers the chip wins - 128x128 run by eight waves once it
+// gives one block per CU, else 128x64 / 64x64 with two resident blocks per CU; layers that
+// cannot reach one block per CU split the taps.  Position-major tiles (see the kernel) only
+// pay off together with the tap split.
+Plan choose_plan(int batch, int hw, int N, const int* force = nullptr) {
+    const int M = batch * hw * hw;
+    // position-major tiles pay off where padding is a visible share of the taps and the
+    // batch fills whole tiles
+    auto pm_ok = [&](int bm) { return hw <= 8 && batch % bm == 0; };
+    if (force && force[0] > 0) {
+        const bool pm = force[3] < 0 ? pm_ok(force[0]) : force[3] > 0;
+        return {force[0], force[1], force[2] > 0 ? force[2] : 1, pm, force[4] > 0 ? force[4] : 4};
+    }
+    auto blocks = [&](int bm, int bn) { return (N % bn) ? 0 : ((M + bm - 1) / bm) * (N / bn); };
+    if (blocks(128, 128) >= 256) return {128, 128, 1, false, 8};
+    if (blocks(128, 64) >= 512) return {128, 64, 1, false, 4};
     const int b = blocks(64, 64);
-    if (b >= 256) return {64, 64, 1};
-    if (b * 3 >= 128) return {64, 64, 3};
-    return {64, 64, 9};
+    if (b > 256) return {64, 64, 1, false, 4};
+    if (blocks(128, 128) * 3 >= 192) return {128, 128, 3, pm_ok(128), 9};
+    if (b >= 256) return {64, 64, 1, false, 4};
+    if (b * 3 >= 128) return {64, 64, 3, pm_ok(64), 4};
+    return {64, 64, 9, pm_ok(64), 4};
 }
 
-template <int BM, int BN, int WAVES_M, int EPI, bool SPLIT, int NS>
+template <int BM, int BN, int WAVES_M, int EPI, bool SPLIT, int NS, bool PM, int NW>
 void launch_one(const IgemmArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int lds = NS * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI, SPLIT, NS>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(
+            (const void*)conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI, SPLIT, NS, PM, NW>,
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI, SPLIT, NS>), grid, dim3(256), lds,
-                       stream, a);
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<BM, BN, WAVES_M, EPI, SPLIT, NS, PM, NW>), grid,
+                       dim3(NW * 64), lds, stream, a);
 }
 
 // LDS stages per tile: 128x128 -> 3 x 32 KiB (one block per CU), 128x64 -> 3 x 24 KiB and
 // 64x64 -> 4 x 16 KiB (two blocks per CU).
-template <int BM, int BN, int WAVES_M, int NS>
-void launch_cfg(const IgemmArgs& a, int epi, int splits, hipStream_t stream) {
-    const int tiles_m = (a.M + BM - 1) / BM;
+template <int BM, int BN, int WAVES_M, int NS, bool PM, int NW>
+void launch_cfg(IgemmArgs a, int epi, int splits, hipStream_t stream) {
+    a.img_blocks = (a.batch + BM - 1) / BM;
+    const int tiles_m = PM ? a.hw * a.hw * a.img_blocks : (a.M + BM - 1) / BM;
     const dim3 grid(tiles_m * a.tiles_n, splits);
     if (splits > 1) {
-        launch_one<BM, BN, WAVES_M, EPI_NONE, true, NS>(a, grid, stream);
+        launch_one<BM, BN, WAVES_M, EPI_NONE, true, NS, PM, NW>(a, grid, stream);
         return;
     }
     switch (epi) {
-        case EPI_NONE: launch_one<BM, BN, WAVES_M, EPI_NONE, false, NS>(a, grid, stream); break;
-        case EPI_BIAS: launch_one<BM, BN, WAVES_M, EPI_BIAS, false, NS>(a, grid, stream); break;
-        case EPI_BIAS_RELU:
-            launch_one<BM, BN, WAVES_M, EPI_BIAS_RELU, false, NS>(a, grid, stream);
+        case EPI_NONE:
+            launch_one<BM, BN, WAVES_M, EPI_NONE, false, NS, PM, NW>(a, grid, stream);
             break;
-        default: launch_one<BM, BN, WAVES_M, EPI_MASK, false, NS>(a, grid, stream); break;
+        case EPI_BIAS:
+            launch_one<BM, BN, WAVES_M, EPI_BIAS, false, NS, PM, NW>(a, grid, stream);
+            break;
+        case EPI_BIAS_RELU:
+            launch_one<BM, BN, WAVES_M, EPI_BIAS_RELU, false, NS, PM, NW>(a, grid, stream);
+            break;
+        default: launch_one<BM, BN, WAVES_M, EPI_MASK, false, NS, PM, NW>(a, grid, stream); break;
     }
+}
+
+template <int BM, int BN, int WAVES_M, int NS, int NW>
+void launch_layout(const IgemmArgs& a, int epi, int splits, bool pm, hipStream_t stream) {
+    if (pm) launch_cfg<BM, BN, WAVES_M, NS, true, NW>(a, epi, splits, stream);
+    else launch_cfg<BM, BN, WAVES_M, NS, false, NW>(a, epi, splits, stream);
 }
 
 void check_shape(const ConvShape& s, const char* who) {
@@ -362,7 +439,7 @@ using namespace igemm;
 
 size_t conv3x3_igemm_workspace_elems(ConvShape s) {
     const int M = s.batch * s.hw * s.hw;
-    const Plan pl = choose_plan(M, s.cout);
+    const Plan pl = choose_plan(s.batch, s.hw, s.cout);
     // room for the widest split so a forced plan (tuning) never outgrows the buffer
     return pl.splits > 1 ? (size_t)9 * M * s.cout : 0;
 }
@@ -378,7 +455,8 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.mask = mask; a.slab = workspace;
     a.M = s.batch * s.hw * s.hw; a.N = s.cout; a.C = s.cin;
     a.hw = s.hw; a.log_hw = ilog2(s.hw); a.log_chunks = ilog2(s.cin / 64);
-    const Plan pl = choose_plan(a.M, a.N, force_plan);
+    a.batch = s.batch; a.img_blocks = 0;
+    const Plan pl = choose_plan(s.batch, s.hw, a.N, force_plan);
     if (!((pl.bm == 128 || pl.bm == 64) && (pl.bn == 128 || pl.bn == 64) && a.N % pl.bn == 0 &&
           (pl.splits == 1 || pl.splits == 3 || pl.splits == 9)) || (pl.bm == 64 && pl.bn == 128))
         throw std::invalid_argument("conv3x3_igemm: unsupported tile plan");
@@ -391,9 +469,16 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
         if (!workspace || workspace_elems < need)
             throw std::invalid_argument("conv3x3_igemm: workspace too small for the tap split");
     }
-    if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 2, 3>(a, epi, pl.splits, stream);
-    else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 2, 3>(a, epi, pl.splits, stream);
-    else launch_cfg<64, 64, 2, 4>(a, epi, pl.splits, stream);
+    if (pl.bm == 128 && pl.bn == 128 && pl.waves == 8)
+        launch_layout<128, 128, 2, 3, 8>(a, epi, pl.splits, pl.pm, stream);
+    else if (pl.bm == 128 && pl.bn == 128 && pl.waves == 9)
+        launch_layout<128, 128, 2, 4, 8>(a, epi, pl.splits, pl.pm, stream);
+    else if (pl.bm == 128 && pl.bn == 128)
+        launch_layout<128, 128, 2, 3, 4>(a, epi, pl.splits, pl.pm, stream);
+    else if (pl.bm == 128 && pl.bn == 64)
+        launch_layout<128, 64, 2, 3, 4>(a, epi, pl.splits, pl.pm, stream);
+    else
+        launch_layout<64, 64, 2, 4, 4>(a, epi, pl.splits, pl.pm, stream);
     if (pl.splits > 1) {
         const size_t total4 = (size_t)a.M * a.N / 4;
         hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256),

@@ -79,6 +79,47 @@ def test_conv3x3_fwd_b256_conv4_and_conv8():
         check(f"fwd {cin}->{cout}@{hw} B256", nchw(y), ref)
 
 
+@pytest.mark.parametrize("batch", [64, 96, 256])
+@pytest.mark.parametrize("cin,cout,hw", [(128, 256, 8), (256, 512, 4), (512, 512, 2), (64, 64, 2)])
+@pytest.mark.parametrize("plan", [(64, 64, 1), (64, 64, 3), (64, 64, 9), (128, 64, 1), (128, 128, 1)])
+def test_conv3x3_position_major_tiles(batch, cin, cout, hw, plan):
+    """Tiles of BM images at one spatial position (padded taps skipped as whole K steps)
+    must give the same result as the pixel-major tiling, for full and ragged image blocks,
+    with and without the tap split."""
+    n = native()
+    bm, bn, splits = plan
+    if cout % bn:
+        pytest.skip("tile wider than the layer")
+    x = rand_bf16(batch, hw, hw, cin, seed=31)
+    w = rand_bf16(cout, 3, 3, cin, scale=(2.0 / (9 * cin)) ** 0.5, seed=32)
+    b = torch.randn(cout, device=DEV) * 0.1
+    ws = torch.empty(9 * batch * hw * hw * cout, device=DEV)
+    y = torch.empty(batch, hw, hw, cout, dtype=torch.bfloat16, device=DEV)
+    s = int(torch.cuda.current_stream().cuda_stream)
+    n.lib().conv3x3_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, ws.data_ptr(),
+                          ws.numel(), batch, hw, cin, cout, n.EPI_BIAS_RELU, s, bm, bn, splits, 1)
+    ref = F.conv2d(nchw(x), oihw(w), b, padding=1).relu()
+    check(f"pm fwd {cin}->{cout}@{hw} B{batch} {plan}", nchw(y), ref)
+
+
+@pytest.mark.parametrize("waves", [8, 9])
+@pytest.mark.parametrize("pm", [0, 1])
+@pytest.mark.parametrize("cin,cout,hw,batch", [(256, 256, 8, 64), (64, 128, 16, 33), (512, 512, 4, 128)])
+def test_conv3x3_eight_wave_tiles(cin, cout, hw, batch, pm, waves):
+    """128x128 tiles run by eight waves (two per SIMD), 3 and 4 LDS stages."""
+    n = native()
+    if pm and (hw > 8 or batch % 128):
+        pytest.skip("position-major tiles need whole image blocks")
+    x = rand_bf16(batch, hw, hw, cin, seed=41)
+    w = rand_bf16(cout, 3, 3, cin, scale=(2.0 / (9 * cin)) ** 0.5, seed=42)
+    b = torch.randn(cout, device=DEV) * 0.1
+    y = torch.empty(batch, hw, hw, cout, dtype=torch.bfloat16, device=DEV)
+    s = int(torch.cuda.current_stream().cuda_stream)
+    n.lib().conv3x3_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, 0, 0, batch, hw,
+                          cin, cout, n.EPI_BIAS, s, 128, 128, 1, pm, waves)
+    check(f"8w fwd {cin}->{cout}@{hw} B{batch}", nchw(y), F.conv2d(nchw(x), oihw(w), b, padding=1))
+
+
 @pytest.mark.parametrize("batch", [2, 32])
 @pytest.mark.parametrize("cin,cout,hw", GENERIC_LAYERS)
 def test_conv3x3_dgrad(batch, cin, cout, hw):

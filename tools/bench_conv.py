@@ -48,6 +48,7 @@ def main():
         ws = torch.empty(9 * M * max(cin, cout), device=DEV)
         plans = [(128, 128, 1), (128, 64, 1), (64, 64, 1), (128, 128, 3), (128, 64, 3), (64, 64, 3),
                  (64, 64, 9), (0, 0, 0)]
+        waves_opts = (4, 8, 9)
         for kind in which:
             if kind == "wgrad":
                 for sp in (0, 1, 2, 4, 8, 16, 32, 64):
@@ -58,20 +59,26 @@ def main():
                     print(f"wgrad {cin:4d}->{cout:4d}@{hw:2d} splits={sp:2d} {t:8.1f} us "
                           f"{flops / t / 1e6:7.1f} TF/s", flush=True)
                 continue
-            for bm, bn, sp in plans:
+            for (bm, bn, sp), pm, nw in itertools.product(plans, (0, 1), waves_opts):
+                if nw != 4 and (bm, bn) != (128, 128):
+                    continue
                 n_out = cout if kind == "fwd" else cin
                 if bn and n_out % bn:
                     continue
+                if pm and (hw > 8 or (bm and B % bm)):
+                    continue
+                if bm == 0:
+                    pm = -1
                 if kind == "fwd":
                     fn = lambda: C.conv3x3_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(),
                                                  bias.data_ptr(), 0, ws.data_ptr(), ws.numel(), B,
-                                                 hw, cin, cout, 2, s, bm, bn, sp)
+                                                 hw, cin, cout, 2, s, bm, bn, sp, pm, nw)
                 else:
                     fn = lambda: C.conv3x3_igemm(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0, 0,
                                                  ws.data_ptr(), ws.numel(), B, hw, cout, cin, 0, s,
-                                                 bm, bn, sp)
+                                                 bm, bn, sp, pm, nw)
                 t = timeit(fn)
-                print(f"{kind:5s} {cin:4d}->{cout:4d}@{hw:2d} plan={bm:3d}x{bn:3d}/{sp} {t:8.1f} us "
+                print(f"{kind:5s} {cin:4d}->{cout:4d}@{hw:2d} plan={bm:3d}x{bn:3d}/{sp} pm={pm:2d} w={nw} {t:8.1f} us "
                       f"{flops / t / 1e6:7.1f} TF/s", flush=True)
 
 

@@ -1,0 +1,49 @@
+"""Per-kernel hardware-counter table from a rocprofv3 --pmc result database (rocpd sqlite).
+
+    python tools/rocpd_pmc.py out/pmc_results.db [--last 1]
+
+Averages each counter over the dispatches of a kernel (optionally only the last N
+dispatches of each distinct (kernel, grid) pair, to drop cold runs).
+"""
+from __future__ import annotations
+
+import argparse
+import sqlite3
+from collections import defaultdict
+
+from rocpd_summary import short
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("db")
+    ap.add_argument("--filter", default="conv")
+    ns = ap.parse_args()
+    con = sqlite3.connect(ns.db)
+    cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
+    want = [c for c in ("dispatch_id", "kernel_name", "name", "counter_name", "value", "grid_size",
+                        "grid_size_x", "workgroup_size", "start", "end") if c in cols]
+    rows = con.execute(f"select {', '.join(want)} from counters_collection").fetchall()
+    idx = {c: i for i, c in enumerate(want)}
+    kcol = idx.get("kernel_name", idx.get("name"))
+    ccol = idx["counter_name"]
+    gcol = idx.get("grid_size", idx.get("grid_size_x"))
+    table = defaultdict(lambda: defaultdict(list))
+    for r in rows:
+        key = (short(str(r[kcol])), r[gcol] if gcol is not None else 0)
+        table[key][r[ccol]].append(float(r[idx["value"]]))
+    counters = sorted({c for v in table.values() for c in v})
+    print(f"{'kernel':60s} {'grid':>9s} " + " ".join(f"{c[-22:]:>22s}" for c in counters))
+    for (name, grid), v in sorted(table.items()):
+        if ns.filter and ns.filter not in name:
+            continue
+        vals = []
+        for c in counters:
+            xs = v.get(c, [])
+            xs = xs[len(xs) // 2:] if len(xs) > 1 else xs        # drop the cold half
+            vals.append(sum(xs) / len(xs) if xs else float("nan"))
+        print(f"{name[:60]:60s} {grid:9d} " + " ".join(f"{x:22.4g}" for x in vals))
+
+
+if __name__ == "__main__":
+    main()
