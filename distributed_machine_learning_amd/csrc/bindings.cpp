@@ -39,16 +39,20 @@ PYBIND11_MODULE(_C, m) {
     m.def("conv3x3_igemm", [](uintptr_t x, uintptr_t w, uintptr_t y, uintptr_t bias, uintptr_t mask,
                               uintptr_t ws, size_t ws_elems, int batch, int hw, int cin, int cout,
                               int epi, uintptr_t stream, int bm, int bn, int splits, int pm,
-                              int waves) {
+                              int waves, uintptr_t stats) {
         const int force[5] = {bm, bn, splits, pm, waves};
         conv3x3_igemm(ptr<const bf16_raw>(x), ptr<const bf16_raw>(w), ptr<bf16_raw>(y),
                       ptr<const float>(bias), ptr<const bf16_raw>(mask), ptr<float>(ws), ws_elems,
                       shape(batch, hw, cin, cout), (ConvEpilogue)epi, st(stream),
-                      bm > 0 ? force : nullptr);
+                      bm > 0 ? force : nullptr, ptr<float>(stats));
     }, py::arg("x"), py::arg("w"), py::arg("y"), py::arg("bias"), py::arg("mask"), py::arg("ws"),
        py::arg("ws_elems"), py::arg("batch"), py::arg("hw"), py::arg("cin"), py::arg("cout"),
        py::arg("epi"), py::arg("stream"), py::arg("bm") = 0, py::arg("bn") = 0,
-       py::arg("splits") = 0, py::arg("pm") = -1, py::arg("waves") = 4);
+       py::arg("splits") = 0, py::arg("pm") = -1, py::arg("waves") = 4, py::arg("stats") = 0);
+    m.def("conv3x3_igemm_stats_rows", [](int batch, int hw, int cin, int cout) {
+        return conv3x3_igemm_stats_rows(shape(batch, hw, cin, cout));
+    });
+    m.def("conv1_fprop_stats_rows", &conv1_fprop_stats_rows);
     m.def("conv3x3_igemm_workspace_elems", [](int batch, int hw, int cin, int cout) {
         return conv3x3_igemm_workspace_elems(shape(batch, hw, cin, cout));
     });
@@ -59,10 +63,11 @@ PYBIND11_MODULE(_C, m) {
     }, py::arg("x"), py::arg("dy"), py::arg("dw"), py::arg("batch"), py::arg("hw"),
        py::arg("cin"), py::arg("cout"), py::arg("stream"), py::arg("splits") = 0);
     m.def("conv1_fprop", [](uintptr_t x, uintptr_t w1, uintptr_t bias, uintptr_t y, int batch,
-                            bool relu, uintptr_t stream) {
+                            bool relu, uintptr_t stream, uintptr_t stats) {
         conv1_fprop(ptr<const bf16_raw>(x), ptr<const bf16_raw>(w1), ptr<const float>(bias),
-                    ptr<bf16_raw>(y), batch, relu, st(stream));
-    });
+                    ptr<bf16_raw>(y), batch, relu, st(stream), ptr<float>(stats));
+    }, py::arg("x"), py::arg("w1"), py::arg("bias"), py::arg("y"), py::arg("batch"),
+       py::arg("relu"), py::arg("stream"), py::arg("stats") = 0);
     m.def("conv1_wgrad", [](uintptr_t x, uintptr_t dy, uintptr_t dw, uintptr_t db, int batch,
                             uintptr_t ws, uintptr_t stream) {
         conv1_wgrad(ptr<const bf16_raw>(x), ptr<const bf16_raw>(dy), ptr<float>(dw), ptr<float>(db),

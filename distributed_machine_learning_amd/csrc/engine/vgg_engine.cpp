@@ -149,6 +149,18 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         slab_elems_ = need_c1 > slab_elems_ ? need_c1 : slab_elems_;
     }
     slab_off_ = w; w = align_up(w + slab_elems_);
+    // BatchNorm statistics partials written by the conv epilogues: rows x [2][cout]
+    cstats_off_ = w;
+    if (bn_) {
+        size_t need = (size_t)conv1_fprop_stats_rows(max_batch_) * 2 * convs_[0].cout;
+        for (size_t i = 1; i < convs_.size(); ++i) {
+            const Conv& c = convs_[i];
+            const size_t n = (size_t)conv3x3_igemm_stats_rows({max_batch_, c.hw, c.cin, c.cout}) *
+                             2 * c.cout;
+            need = n > need ? n : need;
+        }
+        w = align_up(w + need);
+    }
     ws_elems_ = w;
     buckets_by_layer_.assign(convs_.size() + 1, {});
 }
@@ -195,6 +207,12 @@ void VggEngine::refresh_weights(hipStream_t stream) {
     repack_all(stream);
 }
 
+std::vector<long long> VggEngine::bn_save_offsets() const {
+    std::vector<long long> out;
+    for (const Conv& c : convs_) out.push_back(bn_ ? (long long)c.save_off : -1);
+    return out;
+}
+
 std::vector<std::vector<long long>> VggEngine::layer_table() const {
     std::vector<std::vector<long long>> out;
     for (const Conv& c : convs_)
@@ -227,12 +245,21 @@ void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t
     for (size_t i = 0; i < convs_.size(); ++i) {
         const Conv& c = convs_[i];
         uint16_t* dst = arena_ + (bn_ ? c.pre_off : c.out_off);
+        // in training the conv epilogue also leaves the BatchNorm statistics partials
+        BnPartials part;
+        float* cstats = (bn_ && training) ? ws_ + cstats_off_ : nullptr;
         if (i == 0) {
-            conv1_fprop(in, arena_ + w1_off_, params_ + c.b_off, dst, batch, !bn_, stream);
+            conv1_fprop(in, arena_ + w1_off_, params_ + c.b_off, dst, batch, !bn_, stream, cstats);
+            part.rows = conv1_fprop_stats_rows(batch);
         } else {
             ConvShape s = {batch, c.hw, c.cin, c.cout};
             conv3x3_igemm(in, arena_ + shadow_off_ + c.w_off, dst, params_ + c.b_off, nullptr, slab,
-                          slab_elems_, s, bn_ ? EPI_BIAS : EPI_BIAS_RELU, stream);
+                          slab_elems_, s, bn_ ? EPI_BIAS : EPI_BIAS_RELU, stream, nullptr, cstats);
+            if (cstats) part.rows = conv3x3_igemm_stats_rows(s);
+        }
+        if (cstats) {
+            part.data = cstats;
+            part.shift = params_ + c.b_off;
         }
         if (bn_ && c.pool_after) {
             // BatchNorm + ReLU + max-pool in one pass; only the pooled tensor is written
@@ -240,7 +267,8 @@ void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t
                 bn_relu_pool_fwd_train(dst, arena_ + c.pool_off, params_ + c.gamma_off,
                                        params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off,
                                        ws_ + c.save_off, ws_ + c.save_off + c.cout,
-                                       ws_ + stats_off_, batch, c.hw, c.cout, 0.1f, 1e-5f, stream);
+                                       ws_ + stats_off_, batch, c.hw, c.cout, 0.1f, 1e-5f, stream,
+                                       part);
             else
                 bn_relu_pool_fwd_eval(dst, arena_ + c.pool_off, params_ + c.gamma_off,
                                       params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off,
@@ -254,7 +282,7 @@ void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t
                 bn_relu_fwd_train(dst, arena_ + c.out_off, params_ + c.gamma_off,
                                   params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off,
                                   ws_ + c.save_off, ws_ + c.save_off + c.cout, ws_ + stats_off_,
-                                  rows, c.cout, 0.1f, 1e-5f, stream);
+                                  rows, c.cout, 0.1f, 1e-5f, stream, part);
             else
                 bn_relu_fwd_eval(dst, arena_ + c.out_off, params_ + c.gamma_off,
                                  params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off, rows,
@@ -407,6 +435,7 @@ void bind_engine(py::module_& m) {
         .def_property_readonly("buffer_slots", &VggEngine::buffer_slots)
         .def_property_readonly("num_conv", &VggEngine::num_conv)
         .def_property_readonly("layer_table", &VggEngine::layer_table)
+        .def_property_readonly("bn_save_offsets", &VggEngine::bn_save_offsets)
         .def_property("bn_steps", &VggEngine::bn_steps, &VggEngine::set_bn_steps)
         .def("bind", [](VggEngine& e, uintptr_t p, uintptr_t g, uintptr_t mo, uintptr_t bn,
                         uintptr_t arena, uintptr_t ws) {

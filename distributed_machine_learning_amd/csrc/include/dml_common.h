@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace dml {
 
 typedef __bf16 bf16_t;
@@ -57,6 +59,21 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over each aligned group of 16 lanes (one DPP row), result in all 16 lanes: two quad
+// permutes, then half-row and row mirrors - four VALU ops, no LDS traffic.
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp_add = [](float x, auto ctrl) {
+        const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                  0xf, 0xf, true);
+        return x + __builtin_bit_cast(float, y);
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});    // row_mirror
     return v;
 }
 

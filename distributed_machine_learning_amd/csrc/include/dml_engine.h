@@ -86,6 +86,8 @@ class VggEngine {
     int num_conv() const { return (int)convs_.size(); }
     // per conv layer: {cin, cout, hw, pool_after, pre_off, out_off, pool_off} (arena elements)
     std::vector<std::vector<long long>> layer_table() const;
+    // workspace offset of each layer's saved [mean | rstd] (2 * cout floats), -1 without BatchNorm
+    std::vector<long long> bn_save_offsets() const;
     ~VggEngine();
 
   private:
@@ -108,7 +110,8 @@ class VggEngine {
     size_t fcw_off_ = 0, fcb_off_ = 0;
     size_t param_elems_ = 0, bn_elems_ = 0, arena_elems_ = 0, ws_elems_ = 0;
     size_t shadow_off_ = 0, w1_off_ = 0, gbuf_off_[2] = {0, 0};
-    size_t logits_off_ = 0, dlogits_off_ = 0, loss_off_ = 0, stats_off_ = 0, slab_off_ = 0;
+    size_t logits_off_ = 0, dlogits_off_ = 0, loss_off_ = 0, stats_off_ = 0, slab_off_ = 0,
+           cstats_off_ = 0;
     size_t slab_elems_ = 0;
     std::vector<SlotInfo> slots_, bn_slots_;
     float *params_ = nullptr, *grads_ = nullptr, *mom_ = nullptr, *bnbuf_ = nullptr, *ws_ = nullptr;

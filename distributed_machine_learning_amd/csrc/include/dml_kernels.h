@@ -42,13 +42,28 @@ struct ConvShape {
 void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
                    const bf16_raw* mask, float* workspace, size_t workspace_elems,
                    ConvShape s, ConvEpilogue epi, hipStream_t stream,
-                   const int* force_plan = nullptr /* tuning: {BM, BN, splits, position-major (-1 auto), waves} */);
+                   const int* force_plan = nullptr /* tuning: {BM, BN, splits, position-major (-1 auto), waves} */,
+                   float* stats = nullptr);
 size_t conv3x3_igemm_workspace_elems(ConvShape s);
+// With `stats` (EPI_BIAS, default plan) the kernel also leaves per-tile column sums and sums
+// of squares of the BIAS-FREE output: stats[row][0][n], stats[row][1][n] for
+// conv3x3_igemm_stats_rows(s) rows - the BatchNorm statistics without another pass over y
+// (see BnPartials).
+int conv3x3_igemm_stats_rows(ConvShape s);
+
+// Column partial sums handed from a producer kernel to BatchNorm: `rows` rows of [2][c]
+// floats; the mean is shifted by `shift[c]` (the conv bias the partials leave out).
+struct BnPartials {
+    const float* data = nullptr;
+    int rows = 0;
+    const float* shift = nullptr;
+};
 
 // First layer: x is [B,32,32,4] bf16 (3 channels + zero pad), w1 is [64][64] bf16 with
 // k = tap*4 + c (k >= 36 zero), y = relu?(conv + bias) as [B,32,32,64] bf16.
 void conv1_fprop(const bf16_raw* x, const bf16_raw* w1, const float* bias, bf16_raw* y,
-                 int batch, bool relu, hipStream_t stream);
+                 int batch, bool relu, hipStream_t stream, float* stats = nullptr);
+int conv1_fprop_stats_rows(int batch);     // rows of [2][64] floats written to `stats`
 // dW1[64][9][3] += sum_p dy[p][co] * x[p (+) tap][c],  db[64] += sum_p dy[p][co].
 // `ws`: conv1_wgrad_workspace_elems(batch) floats of scratch for the per-block partials.
 void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, int batch,
@@ -75,8 +90,8 @@ void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, Re
 // w1[64][64] bf16 (k = tap*4 + c) from master fp32 [64][9][3]
 void repack_conv1_weights(const float* w, bf16_raw* w1, hipStream_t stream);
 
-// out[c] += sum_m x[m][c].  `ws`: column_sum_workspace_elems() floats, zero before first use
-// (it holds a ticket counter that every launch leaves at zero again).
+// out[c] += sum_m x[m][c].  `ws`: column_sum_workspace_elems() floats of scratch for the
+// per-block partial sums.
 void column_sum(const bf16_raw* x, float* out, int rows, int cols, float* ws, hipStream_t stream);
 size_t column_sum_workspace_elems();
 
@@ -90,11 +105,12 @@ void maxpool2x2_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, int bat
 // ---------------------------------------------------------------- BatchNorm + ReLU (NHWC)
 // Training forward: batch statistics over rows, y = relu(gamma * (x - mean) * rstd + beta),
 // running stats updated with `momentum` (unbiased variance), save_mean/save_rstd kept for
-// backward.  `stats_ws` is bn_workspace_elems() floats, zero before first use.
+// backward.  `stats_ws` is bn_workspace_elems() floats of scratch.  With `from` the statistics
+// pass is skipped and the producer's partial sums are folded instead.
 void bn_relu_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float* save_mean,
                        float* save_rstd, float* stats_ws, int rows, int c, float momentum,
-                       float eps, hipStream_t stream);
+                       float eps, hipStream_t stream, BnPartials from = BnPartials());
 void bn_relu_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, int rows, int c,
                       float eps, hipStream_t stream);
@@ -113,7 +129,7 @@ void bn_relu_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const floa
 void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float* save_mean,
                             float* save_rstd, float* ws, int batch, int hw, int c, float momentum,
-                            float eps, hipStream_t stream);
+                            float eps, hipStream_t stream, BnPartials from = BnPartials());
 void bn_relu_pool_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                            const float* running_mean, const float* running_var, int batch, int hw,
                            int c, float eps, hipStream_t stream);

@@ -54,12 +54,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restric
 __global__ __launch_bounds__(256) void bn_stats_finish_kernel(
     const float* __restrict__ ws, float* __restrict__ save_mean, float* __restrict__ save_rstd,
     float* __restrict__ running_mean, float* __restrict__ running_var, int nb, int rows, int c,
-    float momentum, float eps) {
+    float momentum, float eps, const float* __restrict__ shift) {
     const float inv_n = 1.f / (float)rows;
     column_fold(
         [&](int col, float s1, float s2) {
-            const float mean = s1 * inv_n;
-            const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+            const float m0 = s1 * inv_n;
+            const float var = fmaxf(s2 * inv_n - m0 * m0, 0.f);
+            // partial sums from a conv epilogue leave the bias out: it only moves the mean
+            const float mean = shift ? m0 + shift[col] : m0;
             save_mean[col] = mean;
             save_rstd[col] = rsqrtf(var + eps);
             if (running_mean) {
@@ -70,6 +72,28 @@ __global__ __launch_bounds__(256) void bn_stats_finish_kernel(
         },
         ws, nb, c);
 }
+
+namespace {
+// mean / rstd (+ running statistics) either from a pass over x or from partial sums a
+// producer kernel already left behind
+void batch_statistics(const bf16_raw* x, float* ws, int rows, int c, float* save_mean,
+                      float* save_rstd, float* running_mean, float* running_var, float momentum,
+                      float eps, const BnPartials& from, hipStream_t stream) {
+    if (from.data) {
+        if (from.rows <= 0) throw std::invalid_argument("BatchNorm: empty partial sums");
+        hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
+                           from.data, save_mean, save_rstd, running_mean, running_var, from.rows,
+                           rows, c, momentum, eps, from.shift);
+        return;
+    }
+    const ColReducePlan pl = plan_col_reduce(rows, c);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, c,
+                       pl.rows_per_block);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
+                       (const float*)ws, save_mean, save_rstd, running_mean, running_var, pl.blocks,
+                       rows, c, momentum, eps, (const float*)nullptr);
+}
+}  // namespace
 
 // y = relu(x * scale + shift) with scale = gamma * rstd, shift = beta - mean * scale.  A
 // thread's 8 channels are the same in every grid-stride iteration (the stride is a multiple
@@ -114,14 +138,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 void bn_relu_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float* save_mean,
                        float* save_rstd, float* ws, int rows, int c, float momentum,
-                       float eps, hipStream_t stream) {
+                       float eps, hipStream_t stream, BnPartials from) {
     check(rows, c, "bn_relu_fwd_train");
-    const ColReducePlan pl = plan_col_reduce(rows, c);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, c,
-                       pl.rows_per_block);
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
-                       (const float*)ws, save_mean, save_rstd, running_mean, running_var, pl.blocks,
-                       rows, c, momentum, eps);
+    batch_statistics(x, ws, rows, c, save_mean, save_rstd, running_mean, running_var, momentum, eps,
+                     from, stream);
     const size_t total8 = (size_t)rows * (c / 8);
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(apply_blocks(total8)), dim3(256), 0, stream, x,
                        y, gamma, beta, (const float*)save_mean, (const float*)save_rstd, c, eps,
@@ -424,16 +444,12 @@ PoolGeom pool_geom(int batch, int hw, int c, const char* who) {
 void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float* save_mean,
                             float* save_rstd, float* ws, int batch, int hw, int c, float momentum,
-                            float eps, hipStream_t stream) {
+                            float eps, hipStream_t stream, BnPartials from) {
     const int rows = batch * hw * hw;
     check(rows, c, "bn_relu_pool_fwd_train");
     const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_fwd_train");
-    const ColReducePlan pl = plan_col_reduce(rows, c);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, c,
-                       pl.rows_per_block);
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
-                       (const float*)ws, save_mean, save_rstd, running_mean, running_var, pl.blocks,
-                       rows, c, momentum, eps);
+    batch_statistics(x, ws, rows, c, save_mean, save_rstd, running_mean, running_var, momentum, eps,
+                     from, stream);
     const size_t total8 = (size_t)(rows / 4) * (c / 8);
     hipLaunchKernelGGL(bn_apply_pool_kernel<false>, dim3(apply_blocks(total8)), dim3(256), 0,
                        stream, x, y, gamma, beta, (const float*)save_mean,

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
                                                           const uint16_t* __restrict__ w1,
                                                           const float* __restrict__ bias,
                                                           uint16_t* __restrict__ y, int M,
-                                                          int relu) {
+                                                          int relu, float* __restrict__ stats) {
     __shared__ __attribute__((aligned(16))) char smem[(256 + 64) * 128];
     char* sA = smem;                 // [256 px][64 k]
     char* sB = smem + 256 * 128;     // [64 co][64 k]
@@ -100,6 +100,43 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
+    // optional BatchNorm statistics: column sums / sums of squares of the bias-free output
+    // of this block's 256 pixels (rows past the end multiplied zeros), one row per block
+    if (stats) {
+        float s1[4][4], s2[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[i][j][c];
+                    a += v;
+                    b += v * v;
+                }
+                s1[i][c] = row16_sum(a);
+                s2[i][c] = row16_sum(b);
+            }
+        __syncthreads();
+        float* red = (float*)smem;      // [4 waves][2][64]
+        if (l15 == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    red[(wave * 2 + 0) * 64 + i * 16 + lq * 4 + c] = s1[i][c];
+                    red[(wave * 2 + 1) * 64 + i * 16 + lq * 4 + c] = s2[i][c];
+                }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, col = tid & 63;
+            stats[((size_t)blockIdx.x * 2 + which) * 64 + col] =
+                red[(0 * 2 + which) * 64 + col] + red[(1 * 2 + which) * 64 + col] +
+                red[(2 * 2 + which) * 64 + col] + red[(3 * 2 + which) * 64 + col];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = blockIdx.x * 256 + wave * 64 + j * 16 + l15;
@@ -121,14 +158,16 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
     }
 }
 
+int conv1_fprop_stats_rows(int batch) { return (batch * 1024 + 255) / 256; }
+
 void conv1_fprop(const bf16_raw* x, const bf16_raw* w1, const float* bias, bf16_raw* y, int batch,
-                 bool relu, hipStream_t stream) {
+                 bool relu, hipStream_t stream, float* stats) {
     if (batch <= 0) return;
     if ((long long)batch * 1024 * 128 >= (1LL << 31))
         throw std::invalid_argument("conv1_fprop: batch too large");
     const int M = batch * 1024;
     hipLaunchKernelGGL(conv1_fprop_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, x, w1, bias,
-                       y, M, relu ? 1 : 0);
+                       y, M, relu ? 1 : 0, stats);
 }
 
 // ------------------------------------------------------------------ backward-weight

@@ -38,6 +38,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "dml_column_reduce.h"
 #include "dml_common.h"
 #include "dml_kernels.h"
 
@@ -52,6 +53,7 @@ struct IgemmArgs {
     const float* bias;
     const uint16_t* mask;
     float* slab;          // fp32 [splits][M][N] when splitting
+    float* stats;         // optional per-tile column sums of the bias-free output, [tile_m][2][N]
     int M, N, C;          // pixels, output channels, reduction channels
     int hw, log_hw;       // spatial size
     int log_chunks;       // log2(C / 64)
@@ -269,6 +271,48 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
         compute(s % NS);
     }
 
+    // ---- BatchNorm statistics for free: column sums (and sums of squares) of this tile's
+    // fp32 accumulators, i.e. of the output without its bias (the consumer shifts the mean by
+    // the bias; the variance does not care).  Rows past the end were fed zeros and add
+    // nothing.  One partial row per tile; a fold kernel sums the tiles.
+    if (!SPLIT && p.stats) {
+        float s1[TN][4], s2[TN][4];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const float v = acc[i][j][c];
+                    a += v;
+                    b += v * v;
+                }
+                s1[i][c] = row16_sum(a);
+                s2[i][c] = row16_sum(b);
+            }
+        __syncthreads();                       // every wave is done with the operand stages
+        float* red = (float*)smem;             // [WAVES_M][2][BN]
+        if (l15 == 0) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int col = wn * WTN + i * 16 + lq * 4 + c;
+                    red[(wm * 2 + 0) * BN + col] = s1[i][c];
+                    red[(wm * 2 + 1) * BN + col] = s2[i][c];
+                }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * BN; idx += NW * 64) {
+            const int which = idx / BN, col = idx - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < WAVES_M; ++q) t += red[(q * 2 + which) * BN + col];
+            p.stats[((size_t)tile_m * 2 + which) * p.N + n0 + col] = t;
+        }
+    }
+
     // ---- epilogue: D[n][m]; lane holds n = nb + 4*lq + {0..3}, m = mb + l15
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -340,10 +384,57 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     *(uint2*)(y + off) = o;
 }
 
+// Same sum over the split slabs, organised as a column reduction so the BatchNorm statistics
+// of the (bias-free) result fall out of the pass: thread = 8 columns x strided rows.
+__global__ __launch_bounds__(256) void splitk_finish_stats_kernel(
+    const float* __restrict__ slab, uint16_t* __restrict__ y, const float* __restrict__ bias,
+    float* __restrict__ stats, int M, int N, int splits, size_t slab_stride, int rows_per_block) {
+    __shared__ float red[4096];
+    float bv[8];
+    {
+        const int col0 = (threadIdx.x % (N / 8)) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bv[i] = bias[col0 + i];
+    }
+    column_partials(
+        [&](int r, int cg, float (&a)[8], float (&b)[8]) {
+            const size_t off = (size_t)r * N + cg * 8;
+            float4 lo = *(const float4*)(slab + off), hi = *(const float4*)(slab + off + 4);
+            for (int s = 1; s < splits; ++s) {
+                const float4 l2 = *(const float4*)(slab + s * slab_stride + off);
+                const float4 h2 = *(const float4*)(slab + s * slab_stride + off + 4);
+                lo.x += l2.x; lo.y += l2.y; lo.z += l2.z; lo.w += l2.w;
+                hi.x += h2.x; hi.y += h2.y; hi.z += h2.z; hi.w += h2.w;
+            }
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a[i] += v[i];
+                b[i] += v[i] * v[i];
+                o[i] = v[i] + bv[i];
+            }
+            *(uint4*)(y + off) = pack8(o);
+        },
+        stats, M, N, rows_per_block, red);
+}
+
 int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
     return l;
+}
+
+// rows of `stats` the split path's finishing kernel writes: blocks of ~32 rows per row lane
+ColReducePlan finish_stats_plan(int M, int N) {
+    const int lanes = 256 / (N / 8);
+    int rpb = lanes * 8;
+    int blocks = (M + rpb - 1) / rpb;
+    if (blocks > 512) {
+        rpb = ((M + 511) / 512 + lanes - 1) / lanes * lanes;
+        blocks = (M + rpb - 1) / rpb;
+    }
+    return {blocks, rpb};
 }
 
 struct Plan {
@@ -444,15 +535,27 @@ size_t conv3x3_igemm_workspace_elems(ConvShape s) {
     return pl.splits > 1 ? (size_t)9 * M * s.cout : 0;
 }
 
+int conv3x3_igemm_stats_rows(ConvShape s) {
+    check_shape(s, "conv3x3_igemm_stats_rows");
+    const int M = s.batch * s.hw * s.hw;
+    const Plan pl = choose_plan(s.batch, s.hw, s.cout);
+    if (pl.splits > 1) return finish_stats_plan(M, s.cout).blocks;
+    return pl.pm ? s.hw * s.hw * ((s.batch + pl.bm - 1) / pl.bm) : (M + pl.bm - 1) / pl.bm;
+}
+
 void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
                    const bf16_raw* mask, float* workspace, size_t workspace_elems, ConvShape s,
-                   ConvEpilogue epi, hipStream_t stream, const int* force_plan) {
+                   ConvEpilogue epi, hipStream_t stream, const int* force_plan, float* stats) {
     check_shape(s, "conv3x3_igemm");
     if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias)
         throw std::invalid_argument("conv3x3_igemm: bias epilogue without bias");
     if (epi == EPI_MASK && !mask) throw std::invalid_argument("conv3x3_igemm: mask missing");
     IgemmArgs a;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.mask = mask; a.slab = workspace;
+    a.stats = stats;
+    if (stats && (epi != EPI_BIAS || force_plan))
+        throw std::invalid_argument("conv3x3_igemm: statistics come with the default plan and "
+                                    "the bias-only epilogue");
     a.M = s.batch * s.hw * s.hw; a.N = s.cout; a.C = s.cin;
     a.hw = s.hw; a.log_hw = ilog2(s.hw); a.log_chunks = ilog2(s.cin / 64);
     a.batch = s.batch; a.img_blocks = 0;
@@ -479,7 +582,12 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
         launch_layout<128, 64, 2, 3, 4>(a, epi, pl.splits, pl.pm, stream);
     else
         launch_layout<64, 64, 2, 4, 4>(a, epi, pl.splits, pl.pm, stream);
-    if (pl.splits > 1) {
+    if (pl.splits > 1 && stats) {
+        const ColReducePlan fp = finish_stats_plan(a.M, a.N);
+        hipLaunchKernelGGL(splitk_finish_stats_kernel, dim3(fp.blocks), dim3(256), 0, stream,
+                           (const float*)workspace, y, bias, stats, a.M, a.N, pl.splits,
+                           (size_t)a.M * a.N, fp.rows_per_block);
+    } else if (pl.splits > 1) {
         const size_t total4 = (size_t)a.M * a.N / 4;
         hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256),
                            0, stream, workspace, y, bias, mask, total4, a.N, pl.splits,

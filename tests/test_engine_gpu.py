@@ -166,13 +166,17 @@ def test_engine_layerwise_against_torch(batch_norm):
             gm = bns[L].weight.detach().clone().requires_grad_(True)
             bt = bns[L].bias.detach().clone().requires_grad_(True)
             F.relu(F.batch_norm(p_, None, None, gm, bt, True, 0.1, 1e-5)).backward(g)
-            expect(f"bn{L} dgamma", grads[bn_names[L] + ".weight"], gm.grad, 2e-2)
-            expect(f"bn{L} dbeta", grads[bn_names[L] + ".bias"], bt.grad, 2e-2)
+            expect(f"bn{L} dgamma", grads[bn_names[L] + ".weight"], gm.grad, 4e-2)
+            expect(f"bn{L} dbeta", grads[bn_names[L] + ".bias"], bt.grad, 4e-2)
             g = _bf16(p_.grad)
         if not batch_norm:     # under BatchNorm the conv bias gradient is ~0 (pure rounding noise)
             expect(f"conv{L} db", grads[conv_names[L] + ".bias"], g.sum((0, 2, 3)), 4e-3)
         dw = torch.nn.grad.conv2d_weight(inp_L, (cout, cin, 3, 3), g, padding=1)
-        expect(f"conv{L} dW", grads[conv_names[L] + ".weight"], dw, 8e-3 if batch_norm else 4e-3)
+        # With BatchNorm the engine's batch statistics come from the conv's fp32 accumulators,
+        # the reference's from the bf16-rounded stored output: they agree to ~1e-3 on the
+        # 128-sample layers, and BatchNorm backward (a projection that removes most of g)
+        # turns that into ~1 % on everything upstream.
+        expect(f"conv{L} dW", grads[conv_names[L] + ".weight"], dw, 2.5e-2 if batch_norm else 4e-3)
         if L > 0:
             w = _bf16(convs[L].weight.detach())
             dx = torch.nn.grad.conv2d_input(inp_L.shape, w, g, padding=1)

@@ -120,6 +120,43 @@ def test_conv3x3_eight_wave_tiles(cin, cout, hw, batch, pm, waves):
     check(f"8w fwd {cin}->{cout}@{hw} B{batch}", nchw(y), F.conv2d(nchw(x), oihw(w), b, padding=1))
 
 
+@pytest.mark.parametrize("batch", [3, 32, 256])
+@pytest.mark.parametrize("cin,cout,hw", GENERIC_LAYERS + [(3, 64, 32)])
+def test_conv_epilogue_statistics(batch, cin, cout, hw):
+    """The BatchNorm statistics partials a conv leaves behind: per-channel sum and sum of
+    squares of the bias-free output, over all tiles / finishing blocks."""
+    n = native()
+    C = n.lib()
+    s = int(torch.cuda.current_stream().cuda_stream)
+    b = torch.randn(cout, device=DEV) * 0.1
+    y = torch.empty(batch, hw, hw, cout, dtype=torch.bfloat16, device=DEV)
+    if cin == 3:
+        x = torch.zeros(batch, 32, 32, 4, dtype=torch.bfloat16, device=DEV)
+        x[..., :3] = rand_bf16(batch, 32, 32, 3, seed=51)
+        w = torch.randn(64, 3, 3, 3, device=DEV).to(torch.bfloat16).float() * 0.2
+        rows = C.conv1_fprop_stats_rows(batch)
+        stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
+        C.conv1_fprop(x.data_ptr(), n.pack_conv1_weights(w.contiguous()).data_ptr(), b.data_ptr(),
+                      y.data_ptr(), batch, False, s, stats.data_ptr())
+        ref = F.conv2d(nchw(x[..., :3].contiguous()), w.to(torch.bfloat16).float().permute(0, 3, 1, 2),
+                       None, padding=1)
+    else:
+        x = rand_bf16(batch, hw, hw, cin, seed=51)
+        w = rand_bf16(cout, 3, 3, cin, scale=(2.0 / (9 * cin)) ** 0.5, seed=52)
+        rows = C.conv3x3_igemm_stats_rows(batch, hw, cin, cout)
+        stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
+        need = C.conv3x3_igemm_workspace_elems(batch, hw, cin, cout)
+        ws = torch.empty(max(need, 1), device=DEV)
+        C.conv3x3_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, ws.data_ptr(),
+                        ws.numel(), batch, hw, cin, cout, n.EPI_BIAS, s, 0, 0, 0, -1, 4,
+                        stats.data_ptr())
+        ref = F.conv2d(nchw(x), oihw(w), None, padding=1)
+    check("conv out", nchw(y), ref + b.view(1, -1, 1, 1))
+    tot = stats.sum(0)
+    check("sum", tot[0], ref.sum((0, 2, 3)), rtol=2e-3, atol_scale=2e-3)
+    check("sum of squares", tot[1], (ref * ref).sum((0, 2, 3)), rtol=2e-3, atol_scale=2e-3)
+
+
 @pytest.mark.parametrize("batch", [2, 32])
 @pytest.mark.parametrize("cin,cout,hw", GENERIC_LAYERS)
 def test_conv3x3_dgrad(batch, cin, cout, hw):
