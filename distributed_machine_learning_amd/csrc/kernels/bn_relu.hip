@@ -36,6 +36,12 @@ unsigned apply_blocks(size_t total8) {
 
 size_t bn_workspace_elems() { return kColReduceWsFloats; }
 
+__device__ __forceinline__ void load_consts(const float* __restrict__ p, int col, float (&o)[8]) {
+    const float4 a = *(const float4*)(p + col), b = *(const float4*)(p + col + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
+
 // ----------------------------------------------------------------- forward, training
 __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restrict__ x,
                                                        float* __restrict__ ws, int rows, int c,
@@ -170,12 +176,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     float rs[8], mrs[8], ysc[8], ysh[8];
     {
         const int col0 = (threadIdx.x % (c / 8)) * 8;
+        float gm[8], bt[8], mn[8];
+        load_consts(rstd, col0, rs); load_consts(mean, col0, mn);
+        load_consts(gamma, col0, gm); load_consts(beta, col0, bt);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            rs[i] = rstd[col0 + i];
-            mrs[i] = mean[col0 + i] * rs[i];
-            ysc[i] = gamma[col0 + i] * rs[i];
-            ysh[i] = beta[col0 + i] - gamma[col0 + i] * mrs[i];
+            mrs[i] = mn[i] * rs[i];
+            ysc[i] = gm[i] * rs[i];
+            ysh[i] = bt[i] - gm[i] * mrs[i];
         }
     }
     column_partials(
@@ -291,10 +299,6 @@ __device__ __forceinline__ void load_window(const uint16_t* __restrict__ x, size
     unpack8(q0, v[0]); unpack8(q1, v[1]); unpack8(q2, v[2]); unpack8(q3, v[3]);
 }
 
-__device__ __forceinline__ void load_consts(const float* __restrict__ p, int col, float (&o)[8]) {
-    const float4 a = *(const float4*)(p + col), b = *(const float4*)(p + col + 4);
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-}
 
 template <bool FROM_VAR>
 __global__ __launch_bounds__(256) void bn_apply_pool_kernel(
@@ -352,12 +356,14 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(
     float rs[8], mrs[8], ysc[8], ysh[8];
     {
         const int col0 = (threadIdx.x % (c / 8)) * 8;
+        float gm[8], bt[8], mn[8];
+        load_consts(rstd, col0, rs); load_consts(mean, col0, mn);
+        load_consts(gamma, col0, gm); load_consts(beta, col0, bt);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            rs[i] = rstd[col0 + i];
-            mrs[i] = mean[col0 + i] * rs[i];
-            ysc[i] = gamma[col0 + i] * rs[i];
-            ysh[i] = beta[col0 + i] - gamma[col0 + i] * mrs[i];
+            mrs[i] = mn[i] * rs[i];
+            ysc[i] = gm[i] * rs[i];
+            ysh[i] = bt[i] - gm[i] * mrs[i];
         }
     }
     column_partials(
