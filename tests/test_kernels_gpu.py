@@ -120,6 +120,27 @@ def test_conv3x3_eight_wave_tiles(cin, cout, hw, batch, pm, waves):
     check(f"8w fwd {cin}->{cout}@{hw} B{batch}", nchw(y), F.conv2d(nchw(x), oihw(w), b, padding=1))
 
 
+@pytest.mark.parametrize("batch", [3, 32, 128])
+@pytest.mark.parametrize("cin,cout,hw", GENERIC_LAYERS)
+@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64)])
+def test_conv3x3_patch_resident(batch, cin, cout, hw, tile):
+    """Patch-resident kernel: one LDS copy of the tile's pixels (plus halo) serves all nine
+    taps at nine row shifts, padding handled by per-lane tap masks."""
+    n = native()
+    bm, bn = tile
+    if cout % bn:
+        pytest.skip("tile wider than the layer")
+    x = rand_bf16(batch, hw, hw, cin, seed=61)
+    w = rand_bf16(cout, 3, 3, cin, scale=(2.0 / (9 * cin)) ** 0.5, seed=62)
+    b = torch.randn(cout, device=DEV) * 0.1
+    y = torch.empty(batch, hw, hw, cout, dtype=torch.bfloat16, device=DEV)
+    s = int(torch.cuda.current_stream().cuda_stream)
+    n.lib().conv3x3_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, 0, 0, batch, hw,
+                          cin, cout, n.EPI_BIAS_RELU, s, bm, bn, 1, 0, 16)
+    ref = F.conv2d(nchw(x), oihw(w), b, padding=1).relu()
+    check(f"patch fwd {cin}->{cout}@{hw} B{batch} {tile}", nchw(y), ref)
+
+
 @pytest.mark.parametrize("batch", [3, 32, 256])
 @pytest.mark.parametrize("cin,cout,hw", GENERIC_LAYERS + [(3, 64, 32)])
 def test_conv_epilogue_statistics(batch, cin, cout, hw):
