@@ -38,6 +38,10 @@ std::vector<BucketRange> plan_buckets(const std::vector<size_t>& sizes_bytes, si
 }
 
 namespace {
+// The events only order two streams of ONE device (the RCCL kernel that consumes a bucket
+// runs on this GPU and does its own cross-GPU fencing), so a device-scope release is enough.
+constexpr unsigned kEventFlags = hipEventDisableTiming | hipEventReleaseToDevice;
+
 void check_hip(hipError_t e, const char* what) {
     if (e != hipSuccess)
         throw std::runtime_error(std::string("HIP ") + what + " failed: " + hipGetErrorString(e));
@@ -57,8 +61,8 @@ BucketReducer::BucketReducer(RcclComm* comm, float* flat_grads, std::vector<Slic
     done_.resize(slices_.size());
     launched_.assign(slices_.size(), 0);
     for (size_t i = 0; i < slices_.size(); ++i) {
-        check_hip(hipEventCreateWithFlags(&ready_[i], hipEventDisableTiming), "hipEventCreate");
-        check_hip(hipEventCreateWithFlags(&done_[i], hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&ready_[i], kEventFlags), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&done_[i], kEventFlags), "hipEventCreate");
     }
 }
 
@@ -69,12 +73,16 @@ BucketReducer::~BucketReducer() {
     if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
 }
 
-void BucketReducer::begin_step() { launched_.assign(slices_.size(), 0); }
+void BucketReducer::begin_step() {
+    launched_.assign(slices_.size(), 0);
+    last_ready_ = -1;
+}
 
 void BucketReducer::bucket_ready(int b, hipStream_t compute) {
     if (b < 0 || b >= (int)slices_.size()) throw std::out_of_range("BucketReducer: bucket index");
     if (launched_[b]) throw std::logic_error("BucketReducer: bucket marked ready twice");
     launched_[b] = 1;
+    last_ready_ = b;
     const Slice& s = slices_[b];
     if (serialize_) {       // debug mode: same stream, no overlap, no events
         comm_->all_reduce(grads_ + s.offset, s.count, DT_F32, average_, compute);
@@ -93,13 +101,14 @@ void BucketReducer::bucket_ready(int b, hipStream_t compute) {
 }
 
 void BucketReducer::wait_all(hipStream_t compute) {
-    for (size_t b = 0; b < slices_.size(); ++b) {
+    for (size_t b = 0; b < slices_.size(); ++b)
         if (!launched_[b])
             throw std::logic_error("BucketReducer: backward ended with bucket " +
                                    std::to_string(b) + " never marked ready");
-        if (!serialize_)
-            check_hip(hipStreamWaitEvent(compute, done_[b], 0), "hipStreamWaitEvent(compute)");
-    }
+    // The communication stream runs the buckets in the order they were marked ready, so the
+    // event of the most recent one covers them all: one cross-stream wait, not one per bucket.
+    if (!serialize_ && last_ready_ >= 0)
+        check_hip(hipStreamWaitEvent(compute, done_[last_ready_], 0), "hipStreamWaitEvent(compute)");
 }
 
 void BucketReducer::set_buffer_sync(float* buffers, float* shadow, size_t count) {
@@ -110,7 +119,7 @@ void BucketReducer::set_buffer_sync(float* buffers, float* shadow, size_t count)
     buffers_count_ = count;
     buffers_pending_ = buffers_to_send_ = false;
     if (count && !buffers_done_)
-        check_hip(hipEventCreateWithFlags(&buffers_done_, hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&buffers_done_, kEventFlags), "hipEventCreate");
 }
 
 void BucketReducer::buffers_updated(hipStream_t) {

@@ -140,6 +140,7 @@ class BucketReducer {
     hipStream_t comm_stream_ = nullptr;
     std::vector<hipEvent_t> ready_, done_;
     std::vector<char> launched_;
+    int last_ready_ = -1;
     float* buffers_ = nullptr;
     float* buffers_shadow_ = nullptr;
     size_t buffers_count_ = 0;

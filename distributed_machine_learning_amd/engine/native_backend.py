@@ -60,6 +60,7 @@ class NativeBackend:
             init_state = VGG(cfg.arch, cfg.batch_norm, cfg.num_classes).state_dict()
         self.load_state_dict(init_state)
         self.reducer = None
+        self._grad_scale = 1.0
         self.sync = self._build_sync()
         self._graph_ready = False
         self._x_static = None
@@ -89,8 +90,12 @@ class NativeBackend:
                 end = self.slots[hi - 1].offset + self.slots[hi - 1].numel
                 slices.append((start, end - start))
             self.buckets = buckets
-            self.reducer = C.BucketReducer(comm.native, self.grads.data_ptr(), slices,
-                                           reduce == "mean", cfg.serialize_streams)
+            self._bucket_slices = slices
+            # buckets are summed (RCCL's plain-sum path); the 1/world of "mean" is folded into
+            # the fused SGD kernel's gradient scale, where it is free
+            self.reducer = C.BucketReducer(comm.native, self.grads.data_ptr(), slices, False,
+                                           cfg.serialize_streams)
+            self._grad_scale = 1.0 / self.world if reduce == "mean" else 1.0
             self.engine.set_reducer(self.reducer, buckets)
             if cfg.batch_norm and cfg.broadcast_buffers:
                 # DDP's per-forward buffer broadcast, issued by the reducer after each
@@ -106,6 +111,29 @@ class NativeBackend:
                 self.engine.refresh_weights(self._stream())
             return NoSync(comm, reduce)
         raise ValueError(cfg.sync)
+
+    # ------------------------------------------- communication / compute accounting
+    def set_comm_enabled(self, on: bool) -> None:
+        """Detach (or re-attach) every gradient collective while keeping the rest of the step
+        identical - the compute-only baseline of the overlap report.  Ranks drift apart while
+        detached; only use it for timing."""
+        if on:
+            self.sync = self._sync_saved
+            if self.reducer is not None:
+                self.engine.set_reducer(self.reducer, self.buckets)
+        else:
+            self._sync_saved = self.sync
+            self.sync = NoSync(self.comm, self.cfg.resolved_grad_reduce())
+            if self.reducer is not None:
+                self.engine.set_reducer(None, [])
+
+    def comm_only_step(self) -> None:
+        """Issue exactly the gradient collectives of one step, nothing else."""
+        if self.reducer is not None:
+            for start, count in self._bucket_slices:
+                self.comm.all_reduce(self.grads[start:start + count], "sum")
+        else:
+            self.sync.finish()
 
     # ------------------------------------------------------------------ steps
     @staticmethod
@@ -134,7 +162,7 @@ class NativeBackend:
             return self._train_step_graph(data, target, n, s)
         e.forward_backward(data.data_ptr(), target.data_ptr(), n, s)
         self.sync.finish()
-        e.optimizer_step(cfg.lr, cfg.momentum, cfg.weight_decay, 1.0, s)
+        e.optimizer_step(cfg.lr, cfg.momentum, cfg.weight_decay, self._grad_scale, s)
         return self.workspace[self._loss_off:self._loss_off + 1]
 
     def _train_step_graph(self, data, target, n, s):
@@ -150,7 +178,7 @@ class NativeBackend:
             self._x_static.copy_(data)
             self._t_static.copy_(target)
             e.forward_backward(self._x_static.data_ptr(), self._t_static.data_ptr(), n, s)
-            e.optimizer_step(cfg.lr, cfg.momentum, cfg.weight_decay, 1.0, s)
+            e.optimizer_step(cfg.lr, cfg.momentum, cfg.weight_decay, self._grad_scale, s)
             return self.workspace[self._loss_off:self._loss_off + 1]
         # capture needs a non-default stream; order it after the caller's stream and back
         gs = self._graph_stream
