@@ -57,6 +57,10 @@ def parse():
                          "27 MB bucket that only completes with the last wgrad")
     ap.add_argument("--first-bucket-cap-mb", type=float, default=None,
                     help="defaults to --bucket-cap-mb")
+    ap.add_argument("--tail-bucket-cap-mb", type=float, default=1.0,
+                    help="split the last bucket so that at most this much completes with the "
+                         "final wgrad ({conv4, conv3} then hide behind conv2/conv1 backward and "
+                         "only {conv2, conv1}, 0.3 MB, is exposed)")
     ap.add_argument("--serialize-streams", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
     ap.add_argument("--report-overlap", action="store_true",
@@ -100,6 +104,7 @@ def main():
                       bucket_cap_mb=ns.bucket_cap_mb,
                       first_bucket_cap_mb=(ns.first_bucket_cap_mb if ns.first_bucket_cap_mb
                                            is not None else ns.bucket_cap_mb),
+                      tail_bucket_cap_mb=ns.tail_bucket_cap_mb,
                       serialize_streams=ns.serialize_streams,
                       summary=False, eval=False)
     torch.manual_seed(SEED)
@@ -184,7 +189,7 @@ def main():
                        "mode": ns.mode, "sync": sync, "global_batch": ns.batch_size * world,
                        "batch_per_gpu": ns.batch_size, "image": "3x32x32", "parallelism": par,
                        "optimizer": "SGD lr0.1 m0.9 wd1e-4 (fused)", "backend": backend.name,
-                       "graph": bool(ns.graph), "bucket_cap_mb": ns.bucket_cap_mb,
+                       "graph": bool(ns.graph), "bucket_cap_mb": ns.bucket_cap_mb, "tail_bucket_cap_mb": ns.tail_bucket_cap_mb,
                        "host_enqueue_ms_per_step": round(host_elapsed / probe * 1e3, 4),
                        "final_loss": round(final_loss, 4), "overlap": overlap,
                        "baseline": "reference part3: 305.4 images/s on 4 CPU nodes "

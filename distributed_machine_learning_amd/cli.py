@@ -29,6 +29,7 @@ def build_parser(defaults: TrainConfig, distributed_flags: bool = True) -> argpa
     p.add_argument("--grad-reduce", choices=("sum", "mean"), default=defaults.grad_reduce)
     p.add_argument("--bucket-cap-mb", type=float, default=defaults.bucket_cap_mb)
     p.add_argument("--first-bucket-cap-mb", type=float, default=defaults.first_bucket_cap_mb)
+    p.add_argument("--tail-bucket-cap-mb", type=float, default=defaults.tail_bucket_cap_mb)
     p.add_argument("--batch-size", type=int, default=defaults.batch_size)
     p.add_argument("--iters", type=int, default=defaults.iters)
     p.add_argument("--arch", choices=("VGG11", "VGG13", "VGG16", "VGG19"), default=defaults.arch)

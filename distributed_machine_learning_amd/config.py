@@ -37,6 +37,7 @@ class TrainConfig:
     grad_reduce: Optional[str] = None      # "sum" | "mean"; None -> the mode's reference semantics
     bucket_cap_mb: float = 25.0            # part3/main.py:137
     first_bucket_cap_mb: float = 1.0       # DistributedDataParallel closes its first bucket early
+    tail_bucket_cap_mb: float = 0.0        # > 0: cap the LAST bucket (its all-reduce is exposed)
     broadcast_buffers: bool = True         # DDP default relied on by part3
     comm_timeout_s: float = 300.0
     serialize_streams: bool = False        # debug: run comm on the compute stream

@@ -19,6 +19,7 @@ from ..config import SYNC_ALL_REDUCE, SYNC_DDP, SYNC_GATHER_SCATTER, SYNC_NONE, 
 from ..models.vgg import VGG, VGG_WIDTHS
 from ..ops import native
 from ..parallel.comm import Communicator
+from ..parallel.flat import cap_tail_bucket
 from ..parallel.strategies import AllReduceSync, GatherScatterSync, GradSync, NoSync
 
 
@@ -84,6 +85,7 @@ class NativeBackend:
             sizes = [s.numel * 4 for s in self.slots]
             buckets = C.plan_buckets(sizes, int(cfg.bucket_cap_mb * (1 << 20)),
                                      int(cfg.first_bucket_cap_mb * (1 << 20)))
+            buckets = cap_tail_bucket(buckets, sizes, int(cfg.tail_bucket_cap_mb * (1 << 20)))
             slices = []
             for lo, hi in buckets:
                 start = self.slots[lo].offset

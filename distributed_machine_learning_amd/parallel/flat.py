@@ -106,3 +106,20 @@ def plan_buckets(sizes_bytes: Sequence[int], cap_bytes: int,
     if hi > 0:
         buckets.append((0, hi))
     return buckets
+
+
+def cap_tail_bucket(buckets: List[Tuple[int, int]], sizes_bytes: Sequence[int],
+                    tail_cap_bytes: int) -> List[Tuple[int, int]]:
+    """Split the last bucket (the earliest layers: it completes with the final wgrad, so its
+    all-reduce cannot hide behind backward) so that what remains exposed is at most
+    ``tail_cap_bytes``.  ``buckets`` are ``[lo, hi)`` index ranges in completion order."""
+    if tail_cap_bytes <= 0 or not buckets:
+        return list(buckets)
+    lo, hi = buckets[-1]
+    acc, k = 0, lo
+    while k < hi and acc + sizes_bytes[k] <= tail_cap_bytes:
+        acc += sizes_bytes[k]
+        k += 1
+    if k == lo or k == hi:          # nothing fits, or the bucket is small enough already
+        return list(buckets)
+    return list(buckets[:-1]) + [(k, hi), (lo, k)]

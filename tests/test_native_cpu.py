@@ -82,3 +82,27 @@ def test_engine_layout(bn):
                                                     "layers.1.running_var"] if bn else [])
     with pytest.raises(ValueError):
         C.VggEngine([64, 100], 8, False, 10)
+
+
+def test_tail_bucket_cap_splits_only_the_last_bucket():
+    from distributed_machine_learning_amd.parallel.flat import cap_tail_bucket, plan_buckets
+    from distributed_machine_learning_amd.models.vgg import layer_plan
+    sizes = []
+    for s in layer_plan("VGG11", True):
+        if s.kind == "conv":
+            sizes += [s.cout * s.cin * 9 * 4, s.cout * 4]
+        elif s.kind == "bn":
+            sizes += [s.cout * 4, s.cout * 4]
+        elif s.kind == "fc":
+            sizes += [s.cin * s.cout * 4, s.cout * 4]
+    cap = 12 << 20
+    buckets = plan_buckets(sizes, cap, cap)
+    assert len(buckets) == 3
+    split = cap_tail_bucket(buckets, sizes, 1 << 20)
+    assert split[:2] == buckets[:2] and len(split) == 4
+    (k, hi), (lo, k2) = split[2], split[3]
+    assert lo == 0 and k == k2 and hi == buckets[2][1]
+    assert sum(sizes[lo:k]) <= 1 << 20 < sum(sizes[lo:k + 1])
+    covered = sorted(i for a, b in split for i in range(a, b))
+    assert covered == list(range(len(sizes)))
+    assert cap_tail_bucket(buckets, sizes, 0) == buckets
