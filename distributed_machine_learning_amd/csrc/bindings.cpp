@@ -57,11 +57,29 @@ PYBIND11_MODULE(_C, m) {
         return conv3x3_igemm_workspace_elems(shape(batch, hw, cin, cout));
     });
     m.def("conv3x3_wgrad", [](uintptr_t x, uintptr_t dy, uintptr_t dw, int batch, int hw, int cin,
-                              int cout, uintptr_t stream, int splits) {
+                              int cout, uintptr_t stream, int splits, uintptr_t slab) {
         conv3x3_wgrad(ptr<const bf16_raw>(x), ptr<const bf16_raw>(dy), ptr<float>(dw),
-                      shape(batch, hw, cin, cout), st(stream), splits);
+                      shape(batch, hw, cin, cout), st(stream), splits, ptr<float>(slab));
     }, py::arg("x"), py::arg("dy"), py::arg("dw"), py::arg("batch"), py::arg("hw"),
-       py::arg("cin"), py::arg("cout"), py::arg("stream"), py::arg("splits") = 0);
+       py::arg("cin"), py::arg("cout"), py::arg("stream"), py::arg("splits") = 0,
+       py::arg("slab") = 0);
+    m.def("conv3x3_wgrad_splits", [](int batch, int hw, int cin, int cout) {
+        return conv3x3_wgrad_splits(shape(batch, hw, cin, cout));
+    });
+    m.def("sum_slabs_batch", [](uintptr_t src, uintptr_t dst, std::vector<size_t> src_off,
+                                std::vector<size_t> dst_off, std::vector<size_t> count,
+                                std::vector<int> splits, uintptr_t stream) {
+        SlabSumJobs jobs;
+        if (src_off.size() > (size_t)SlabSumJobs::kMax || src_off.size() != dst_off.size() ||
+            src_off.size() != count.size() || src_off.size() != splits.size())
+            throw std::invalid_argument("sum_slabs_batch: bad job lists");
+        jobs.n = (int)src_off.size();
+        for (int j = 0; j < jobs.n; ++j) {
+            jobs.src_off[j] = src_off[j]; jobs.dst_off[j] = dst_off[j];
+            jobs.count[j] = count[j]; jobs.splits[j] = splits[j];
+        }
+        sum_slabs_batch(ptr<const float>(src), ptr<float>(dst), jobs, st(stream));
+    });
     m.def("conv1_fprop", [](uintptr_t x, uintptr_t w1, uintptr_t bias, uintptr_t y, int batch,
                             bool relu, uintptr_t stream, uintptr_t stats) {
         conv1_fprop(ptr<const bf16_raw>(x), ptr<const bf16_raw>(w1), ptr<const float>(bias),

@@ -161,6 +161,15 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         }
         w = align_up(w + need);
     }
+    // wgrad partial results, one slab per split (summed by a batched kernel: deterministic,
+    // and plain stores run ~4x faster than float atomics)
+    for (size_t i = 0; i < convs_.size(); ++i) {
+        Conv& c = convs_[i];
+        c.wslab_off = w;
+        if (i == 0) continue;
+        const int splits = conv3x3_wgrad_splits({max_batch_, c.hw, c.cin, c.cout});
+        if (splits > 1) w = align_up(w + (size_t)splits * c.cout * 9 * c.cin);
+    }
     ws_elems_ = w;
     buckets_by_layer_.assign(convs_.size() + 1, {});
 }
@@ -194,8 +203,15 @@ void VggEngine::set_reducer(BucketReducer* reducer, const std::vector<BucketRang
 }
 
 void VggEngine::fire_buckets(int layer, hipStream_t stream) {
-    if (!reducer_) return;
+    if (!reducer_ || buckets_by_layer_[layer].empty()) return;
+    flush_wgrad_sums(stream);       // a bucket leaves with complete gradients
     for (int b : buckets_by_layer_[layer]) reducer_->bucket_ready(b, stream);
+}
+
+void VggEngine::flush_wgrad_sums(hipStream_t stream) {
+    if (wgrad_sums_.n == 0) return;
+    sum_slabs_batch(ws_, grads_, wgrad_sums_, stream);
+    wgrad_sums_.n = 0;
 }
 
 void VggEngine::refresh_weights(hipStream_t stream) {
@@ -346,7 +362,16 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             // normalisation removes any per-channel offset; a framework's value there is
             // rounding noise), so it is left at the zero the gradient memset wrote.
             if (!bn_) column_sum(g, grads_ + c.b_off, rows, c.cout, ws_ + stats_off_, stream);
-            conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream);
+            conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream, 0, ws_ + c.wslab_off);
+            const int splits = conv3x3_wgrad_splits(s);
+            if (splits > 1) {
+                if (wgrad_sums_.n == SlabSumJobs::kMax) flush_wgrad_sums(stream);
+                const int j = wgrad_sums_.n++;
+                wgrad_sums_.src_off[j] = c.wslab_off;
+                wgrad_sums_.dst_off[j] = c.w_off;
+                wgrad_sums_.count[j] = (size_t)c.cout * 9 * c.cin;
+                wgrad_sums_.splits[j] = splits;
+            }
             // input gradient; the producer's ReLU is folded in when nothing sits in between
             ConvShape d = {batch, c.hw, c.cout, c.cin};
             const bool fold_relu = !prev.pool_after && !bn_;
@@ -357,12 +382,17 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
         }
         fire_buckets(i, stream);
     }
+    flush_wgrad_sums(stream);
 }
 
 void VggEngine::forward_backward(const uint16_t* x, const int64_t* target, int batch,
                                  hipStream_t stream) {
     if (!params_) throw std::logic_error("VggEngine: bind() first");
-    check_hip(hipMemsetAsync(grads_, 0, param_elems_ * sizeof(float), stream), "memset(grads)");
+    // Only the classifier's gradients are accumulated with atomics and need a zero start;
+    // everything else is overwritten (conv biases under BatchNorm are never written and keep
+    // the zero they were allocated with).
+    check_hip(hipMemsetAsync(grads_ + fcw_off_, 0, (param_elems_ - fcw_off_) * sizeof(float), stream),
+              "memset(fc grads)");
     check_hip(hipMemsetAsync(ws_ + loss_off_, 0, sizeof(float), stream), "memset(loss)");
     if (reducer_) {
         reducer_->begin_step();

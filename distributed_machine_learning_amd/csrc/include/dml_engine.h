@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "dml_comm.h"
+#include "dml_kernels.h"
 
 namespace pybind11 { class module_; }
 
@@ -98,10 +99,12 @@ class VggEngine {
         size_t rm_off, rv_off;                        // bn_buffers
         size_t save_off;                              // workspace: mean[c], rstd[c]
         size_t wd_off;                                // arena: dgrad-layout weights
+        size_t wslab_off;                             // workspace: wgrad partial results per split
         size_t pre_off, out_off, pool_off;            // arena: activations
     };
     void backward(const uint16_t* x_nhwc4, const int64_t* target, int batch, hipStream_t stream);
     void fire_buckets(int layer, hipStream_t stream);
+    void flush_wgrad_sums(hipStream_t stream);
     void repack_all(hipStream_t stream);
 
     std::vector<Conv> convs_;
@@ -112,6 +115,7 @@ class VggEngine {
     size_t shadow_off_ = 0, w1_off_ = 0, gbuf_off_[2] = {0, 0};
     size_t logits_off_ = 0, dlogits_off_ = 0, loss_off_ = 0, stats_off_ = 0, slab_off_ = 0,
            cstats_off_ = 0;
+    SlabSumJobs wgrad_sums_;      // partial-result reductions not yet launched
     size_t slab_elems_ = 0;
     std::vector<SlotInfo> slots_, bn_slots_;
     float *params_ = nullptr, *grads_ = nullptr, *mom_ = nullptr, *bnbuf_ = nullptr, *ws_ = nullptr;

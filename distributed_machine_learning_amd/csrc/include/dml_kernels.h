@@ -64,16 +64,31 @@ struct BnPartials {
 void conv1_fprop(const bf16_raw* x, const bf16_raw* w1, const float* bias, bf16_raw* y,
                  int batch, bool relu, hipStream_t stream, float* stats = nullptr);
 int conv1_fprop_stats_rows(int batch);     // rows of [2][64] floats written to `stats`
-// dW1[64][9][3] += sum_p dy[p][co] * x[p (+) tap][c],  db[64] += sum_p dy[p][co].
+// dW1[64][9][3] = sum_p dy[p][co] * x[p (+) tap][c],  db[64] = sum_p dy[p][co]  (overwritten).
 // `ws`: conv1_wgrad_workspace_elems(batch) floats of scratch for the per-block partials.
 void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, int batch,
                  float* ws, hipStream_t stream);
 size_t conv1_wgrad_workspace_elems(int batch);
 
-// dw[cout][9][cin] (+)= sum_p dy[p][cout] * x[p (+) tap][cin]   (fp32).  With more than one
-// split the kernel accumulates with atomics and `dw` must be zeroed by the caller.
+// dw[cout][9][cin] (+)= sum_p dy[p][cout] * x[p (+) tap][cin]   (fp32).  The pixel range is
+// split over conv3x3_wgrad_splits(s) blocks per tile.  Without `slab` the splits accumulate
+// into `dw` with atomics (zero it first).  With `slab` (splits * cout*9*cin floats) every
+// split stores its partial result there instead - plain stores, deterministic - and the
+// caller sums them (sum_slabs_batch); with a single split `dw` is written directly.
 void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
-                   hipStream_t stream, int force_splits = 0 /* tuning */);
+                   hipStream_t stream, int force_splits = 0 /* tuning */, float* slab = nullptr);
+int conv3x3_wgrad_splits(ConvShape s);
+
+// dst[job][i] = sum_k src[job][k * count + i] for up to 32 jobs in one launch (offsets in
+// floats from the two bases, counts multiples of 4): the reduction behind the slab mode above.
+struct SlabSumJobs {
+    static constexpr int kMax = 32;
+    int n = 0;
+    size_t src_off[kMax], dst_off[kMax], count[kMax];
+    int splits[kMax];
+    unsigned block_start[kMax + 1];     // filled by the launcher
+};
+void sum_slabs_batch(const float* src_base, float* dst_base, SlabSumJobs jobs, hipStream_t stream);
 
 // wd[cin][8 - tap][cout] = wf[cout][tap][cin]   (bf16 -> bf16)
 void repack_dgrad_weights(const bf16_raw* wf, bf16_raw* wd, int cout, int cin, hipStream_t stream);
@@ -90,7 +105,7 @@ void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, Re
 // w1[64][64] bf16 (k = tap*4 + c) from master fp32 [64][9][3]
 void repack_conv1_weights(const float* w, bf16_raw* w1, hipStream_t stream);
 
-// out[c] += sum_m x[m][c].  `ws`: column_sum_workspace_elems() floats of scratch for the
+// out[c] = sum_m x[m][c] (overwritten).  `ws`: column_sum_workspace_elems() floats of scratch for the
 // per-block partial sums.
 void column_sum(const bf16_raw* x, float* out, int rows, int cols, float* ws, hipStream_t stream);
 size_t column_sum_workspace_elems();

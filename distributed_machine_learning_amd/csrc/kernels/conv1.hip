@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
     }
 }
 
-// dw[co][tap][c] += sum_blocks slab[b][co][tap*4+c] (c < 3), db[co] += sum_blocks slab[b][co][36].
+// dw[co][tap][c] = sum_blocks slab[b][co][tap*4+c] (c < 3), db[co] = sum_blocks slab[b][co][36].
 // Grid: 40 blocks of 64 outputs; 4 lanes per output each fold a quarter of the slab rows.
 __global__ __launch_bounds__(256) void conv1_wgrad_finish_kernel(const float* __restrict__ slab,
                                                                  float* __restrict__ dw,
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_finish_kernel(const float* __
                         red[3][threadIdx.x];
         const int co = o / 40, k = o % 40;
         const int tap = k >> 2, c = k & 3;
-        if (tap < 9 && c < 3) dw[co * 27 + tap * 3 + c] += v;
-        else if (k == 36 && db) db[co] += v;
+        if (tap < 9 && c < 3) dw[co * 27 + tap * 3 + c] = v;
+        else if (k == 36 && db) db[co] = v;
     }
 }
 

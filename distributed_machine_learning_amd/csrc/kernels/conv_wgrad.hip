@@ -55,6 +55,7 @@ struct WgradArgs {
     int tiles_ci, tiles_co;
     int steps_per_split;   // K steps (64 pixels each) per blockIdx.y
     int atomic;
+    size_t split_stride;   // elements between the partial results of consecutive splits (slab mode)
     unsigned x_bytes, dy_bytes;   // extents for the buffer descriptors
 };
 
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float* dst = p.dw + ((size_t)co * 9 + tap) * p.Cin + ci;
+                float* dst = p.dw + blockIdx.y * p.split_stride + ((size_t)co * 9 + tap) * p.Cin + ci;
                 if (p.atomic) atomicAdd(dst, acc[i][j][r]);
                 else *dst = acc[i][j][r];
             }
@@ -207,21 +208,38 @@ int ilog2w(int v) {
     return l;
 }
 
-template <int BCO, int BCI>
-void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits) {
-    a.tiles_co = a.Cout / BCO;
-    a.tiles_ci = a.Cin / BCI;
-    const int tiles = a.tiles_co * a.tiles_ci * 9;
-    const int total_steps = (a.M + 63) / 64;
-    // split the pixel range until ~1.1 blocks per CU, keeping >= 4 K steps per block
+// Pixel-range splits: until the grid has ~1.1 blocks per CU, keeping >= 4 K steps per block.
+struct SplitPlan { int splits, steps_per_split; };
+SplitPlan plan_splits(int M, int tiles, int force_splits) {
+    const int total_steps = (M + 63) / 64;
     int splits = (288 + tiles - 1) / tiles;
     const int max_splits = total_steps >= 4 ? total_steps / 4 : 1;
     if (splits > max_splits) splits = max_splits;
     if (force_splits > 0) splits = force_splits < total_steps ? force_splits : total_steps;
     if (splits < 1) splits = 1;
-    a.steps_per_split = (total_steps + splits - 1) / splits;
-    splits = (total_steps + a.steps_per_split - 1) / a.steps_per_split;
-    a.atomic = splits > 1 ? 1 : 0;
+    const int sps = (total_steps + splits - 1) / splits;
+    return {(total_steps + sps - 1) / sps, sps};
+}
+
+int wgrad_tiles(const ConvShape& s) {
+    const int bco = s.cout % 128 == 0 ? 128 : 64, bci = s.cin % 128 == 0 ? 128 : 64;
+    return (s.cout / bco) * (s.cin / bci) * 9;
+}
+
+template <int BCO, int BCI>
+void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab) {
+    a.tiles_co = a.Cout / BCO;
+    a.tiles_ci = a.Cin / BCI;
+    const int tiles = a.tiles_co * a.tiles_ci * 9;
+    const SplitPlan sp = plan_splits(a.M, tiles, force_splits);
+    a.steps_per_split = sp.steps_per_split;
+    a.split_stride = 0;
+    a.atomic = sp.splits > 1 ? 1 : 0;
+    if (slab && sp.splits > 1) {        // deterministic: one partial result per split, no atomics
+        a.dw = slab;
+        a.split_stride = (size_t)a.Cout * 9 * a.Cin;
+        a.atomic = 0;
+    }
     constexpr int lds = 2 * 64 * ((BCO * 2 + 64) + (BCI * 2 + 64));
     static bool attr_set = false;
     if (!attr_set) {
@@ -229,14 +247,18 @@ void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<BCO, BCI>), dim3(tiles, splits), dim3(256), lds,
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<BCO, BCI>), dim3(tiles, sp.splits), dim3(256), lds,
                        stream, a);
 }
 
 }  // namespace
 
+int conv3x3_wgrad_splits(ConvShape s) {
+    return plan_splits(s.batch * s.hw * s.hw, wgrad_tiles(s), 0).splits;
+}
+
 void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
-                   hipStream_t stream, int force_splits) {
+                   hipStream_t stream, int force_splits, float* slab) {
     if (s.batch <= 0 || s.hw < 1 || s.hw > 32 || (s.hw & (s.hw - 1)) || s.cin % 64 ||
         s.cout % 64 || s.cin < 64 || s.cout < 64)
         throw std::invalid_argument("conv3x3_wgrad: needs hw power of two <= 32, cin % 64 == 0, "
@@ -245,17 +267,17 @@ void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s
     a.x = x; a.dy = dy; a.dw = dw;
     a.M = s.batch * s.hw * s.hw; a.Cin = s.cin; a.Cout = s.cout;
     a.hw = s.hw; a.log_hw = ilog2w(s.hw);
-    a.tiles_ci = a.tiles_co = 0; a.steps_per_split = 0; a.atomic = 0;
+    a.tiles_ci = a.tiles_co = 0; a.steps_per_split = 0; a.atomic = 0; a.split_stride = 0;
     if ((long long)a.M * (s.cin > s.cout ? s.cin : s.cout) >= (1LL << 30))
         throw std::invalid_argument("conv3x3_wgrad: tensor exceeds 2^31 bytes");
     a.x_bytes = (unsigned)((size_t)a.M * s.cin * 2);
     a.dy_bytes = (unsigned)((size_t)a.M * s.cout * 2);
     if (s.cout % 128 == 0) {
-        if (s.cin % 128 == 0) launch_wgrad<128, 128>(a, stream, force_splits);
-        else launch_wgrad<128, 64>(a, stream, force_splits);
+        if (s.cin % 128 == 0) launch_wgrad<128, 128>(a, stream, force_splits, slab);
+        else launch_wgrad<128, 64>(a, stream, force_splits, slab);
     } else {        // 64-channel layers of the deeper VGG variants (64 -> 64 at 32x32)
-        if (s.cin % 128 == 0) launch_wgrad<64, 128>(a, stream, force_splits);
-        else launch_wgrad<64, 64>(a, stream, force_splits);
+        if (s.cin % 128 == 0) launch_wgrad<64, 128>(a, stream, force_splits, slab);
+        else launch_wgrad<64, 64>(a, stream, force_splits, slab);
     }
 }
 

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const uint16_t* __restr
 __global__ __launch_bounds__(256) void column_sum_finish_kernel(const float* __restrict__ ws,
                                                                 float* __restrict__ out, int nb,
                                                                 int c) {
-    column_fold([&](int col, float s1, float) { out[col] += s1; }, ws, nb, c);
+    column_fold([&](int col, float s1, float) { out[col] = s1; }, ws, nb, c);
 }
 
 size_t column_sum_workspace_elems() { return kColReduceWsFloats; }
@@ -245,6 +245,50 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(float4* __restrict__ sla
         }
         slabs[i] = a;
     }
+}
+
+// Batched form for the wgrad partial results: job j owns blocks [block_start[j],
+// block_start[j+1]), a thread sums one float4 column over the job's splits with eight loads in
+// flight (the kernel is a pure stream: splits * count floats in, count out).
+__global__ __launch_bounds__(256) void sum_slabs_batch_kernel(const float* __restrict__ src_base,
+                                                              float* __restrict__ dst_base,
+                                                              SlabSumJobs jobs) {
+    int j = 0;
+    while (j + 1 < jobs.n && blockIdx.x >= jobs.block_start[j + 1]) ++j;
+    const size_t n4 = jobs.count[j] / 4;
+    const size_t i = (size_t)(blockIdx.x - jobs.block_start[j]) * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4* src = (const float4*)(src_base + jobs.src_off[j]) + i;
+    const int splits = jobs.splits[j];
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(k + q) * n4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+    }
+    for (; k < splits; ++k) {
+        const float4 v = src[(size_t)k * n4];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    ((float4*)(dst_base + jobs.dst_off[j]))[i] = a;
+}
+
+void sum_slabs_batch(const float* src_base, float* dst_base, SlabSumJobs jobs, hipStream_t stream) {
+    if (jobs.n <= 0) return;
+    if (jobs.n > SlabSumJobs::kMax) throw std::invalid_argument("sum_slabs_batch: too many jobs");
+    unsigned blocks = 0;
+    for (int j = 0; j < jobs.n; ++j) {
+        if (jobs.count[j] % 4 || jobs.src_off[j] % 4 || jobs.dst_off[j] % 4 || jobs.splits[j] < 1)
+            throw std::invalid_argument("sum_slabs_batch: counts and offsets must be multiples of 4");
+        jobs.block_start[j] = blocks;
+        blocks += (unsigned)((jobs.count[j] / 4 + 255) / 256);
+    }
+    jobs.block_start[jobs.n] = blocks;
+    hipLaunchKernelGGL(sum_slabs_batch_kernel, dim3(blocks), dim3(256), 0, stream, src_base,
+                       dst_base, jobs);
 }
 
 void sum_slabs(float* slabs, int world, size_t n, hipStream_t stream) {

@@ -209,6 +209,32 @@ def test_conv3x3_wgrad(batch, cin, cout, hw):
           atol_scale=2e-3)
 
 
+@pytest.mark.parametrize("cin,cout,hw,batch", [(64, 128, 16, 64), (256, 256, 8, 256), (512, 512, 2, 256)])
+def test_conv3x3_wgrad_slab_mode_is_deterministic(cin, cout, hw, batch):
+    """Per-split partial results + the batched slab sum: same numbers as the atomic path,
+    and bit-identical from run to run."""
+    n = native()
+    C = n.lib()
+    s = int(torch.cuda.current_stream().cuda_stream)
+    x = rand_bf16(batch, hw, hw, cin, seed=71)
+    dy = rand_bf16(batch, hw, hw, cout, seed=72)
+    splits = C.conv3x3_wgrad_splits(batch, hw, cin, cout)
+    assert splits > 1
+    count = cout * 9 * cin
+    outs = []
+    for _ in range(2):
+        slab = torch.full((splits * count,), float("nan"), device=DEV)
+        dw = torch.full((count + 64,), float("nan"), device=DEV)
+        C.conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), batch, hw, cin, cout, s, 0,
+                        slab.data_ptr())
+        C.sum_slabs_batch(slab.data_ptr(), dw.data_ptr(), [0], [0], [count], [splits], s)
+        assert bool(torch.isnan(dw[count:]).all())
+        outs.append(dw[:count].view(cout, 3, 3, cin).clone())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.nn.grad.conv2d_weight(nchw(x), (cout, cin, 3, 3), nchw(dy), padding=1)
+    check("wgrad slab", outs[0].permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=2e-3)
+
+
 def test_conv3x3_wgrad_b256():
     n = native()
     for cin, cout, hw in [(64, 128, 16), (512, 512, 2)]:
