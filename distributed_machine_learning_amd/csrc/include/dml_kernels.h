@@ -71,10 +71,11 @@ void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, in
 size_t conv1_wgrad_workspace_elems(int batch);
 
 // dw[cout][9][cin] (+)= sum_p dy[p][cout] * x[p (+) tap][cin]   (fp32).  The pixel range is
-// split over conv3x3_wgrad_splits(s) blocks per tile.  Without `slab` the splits accumulate
-// into `dw` with atomics (zero it first).  With `slab` (splits * cout*9*cin floats) every
+// split over several blocks per tile.  Without `slab` the splits accumulate into `dw` with
+// atomics (zero it first).  With `slab` (splits * cout*9*cin floats) every
 // split stores its partial result there instead - plain stores, deterministic - and the
-// caller sums them (sum_slabs_batch); with a single split `dw` is written directly.
+// caller sums the conv3x3_wgrad_splits(s) partials (sum_slabs_batch); with a single split `dw`
+// is written directly.
 void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
                    hipStream_t stream, int force_splits = 0 /* tuning */, float* slab = nullptr);
 int conv3x3_wgrad_splits(ConvShape s);

@@ -208,11 +208,15 @@ int ilog2w(int v) {
     return l;
 }
 
-// Pixel-range splits: until the grid has ~1.1 blocks per CU, keeping >= 4 K steps per block.
+// Pixel-range splits, keeping >= 4 K steps per block.  Measured optimum on MI355X (batch
+// 256, tools/bench_conv.py): with atomic accumulation ~1.1 blocks per CU (every further split
+// adds |dw| of atomic traffic); with per-split slabs, where a split only costs plain stores,
+// ~1.7 blocks per CU (432 blocks: two 80 KB-LDS blocks share most CUs).
 struct SplitPlan { int splits, steps_per_split; };
-SplitPlan plan_splits(int M, int tiles, int force_splits) {
+SplitPlan plan_splits(int M, int tiles, int force_splits, bool slab_mode = true) {
     const int total_steps = (M + 63) / 64;
-    int splits = (288 + tiles - 1) / tiles;
+    const int target = slab_mode ? 432 : 288;
+    int splits = slab_mode ? (target + tiles / 2) / tiles : (target + tiles - 1) / tiles;
     const int max_splits = total_steps >= 4 ? total_steps / 4 : 1;
     if (splits > max_splits) splits = max_splits;
     if (force_splits > 0) splits = force_splits < total_steps ? force_splits : total_steps;
@@ -231,7 +235,7 @@ void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab
     a.tiles_co = a.Cout / BCO;
     a.tiles_ci = a.Cin / BCI;
     const int tiles = a.tiles_co * a.tiles_ci * 9;
-    const SplitPlan sp = plan_splits(a.M, tiles, force_splits);
+    const SplitPlan sp = plan_splits(a.M, tiles, force_splits, slab != nullptr);
     a.steps_per_split = sp.steps_per_split;
     a.split_stride = 0;
     a.atomic = sp.splits > 1 ? 1 : 0;
@@ -254,7 +258,7 @@ void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab
 }  // namespace
 
 int conv3x3_wgrad_splits(ConvShape s) {
-    return plan_splits(s.batch * s.hw * s.hw, wgrad_tiles(s), 0).splits;
+    return plan_splits(s.batch * s.hw * s.hw, wgrad_tiles(s), 0, true).splits;
 }
 
 void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
