@@ -15,7 +15,7 @@
 
 namespace dml {
 
-constexpr int kColReduceSlabFloats = 65536;                        // 256 KiB
+constexpr int kColReduceSlabFloats = 131072;                       // 512 KiB
 constexpr int kColReduceWsFloats = kColReduceSlabFloats;
 
 struct ColReducePlan {
@@ -23,13 +23,13 @@ struct ColReducePlan {
 };
 
 // About 4 rows per thread - all of a thread's loads in flight at once, these kernels are
-// latency-bound on every layer but the first - at most 256 blocks, slab (blocks * 2c floats)
-// within 256 KiB, rows_per_block a multiple of the row lanes of a block.
+// latency-bound on every layer but the first - at most 512 blocks (two per CU), slab
+// (blocks * 2c floats) within 512 KiB, rows_per_block a multiple of the row lanes of a block.
 inline ColReducePlan plan_col_reduce(int rows, int c) {
     const int lanes = 256 / (c / 8);
     long long want = (rows + lanes * 4 - 1) / (lanes * 4);
     if (want < 1) want = 1;
-    if (want > 256) want = 256;
+    if (want > 512) want = 512;
     const int cap = kColReduceSlabFloats / (2 * c);
     if (want > cap) want = cap;
     int rpb = (int)((rows + want - 1) / want);

@@ -25,14 +25,6 @@ namespace {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_c1;
 
-// im2col taps (t0, t0+1) of pixel `pix` as one 16-byte chunk; tap index >= 9 gives zeros.
-__device__ __forceinline__ uint2 load_tap(const uint16_t* x, int pix, int h, int w, int tap,
-                                          bool row_ok) {
-    const int dh = tap / 3 - 1, dw = tap % 3 - 1;
-    const bool ok = row_ok && tap < 9 && (unsigned)(h + dh) < 32u && (unsigned)(w + dw) < 32u;
-    return ok ? *(const uint2*)(x + (size_t)(pix + dh * 32 + dw) * 4) : make_uint2(0, 0);
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------- forward

@@ -44,7 +44,10 @@ def resolve_device(cfg: TrainConfig, local_rank: int = 0) -> torch.device:
 def resolve_backend(cfg: TrainConfig, device: torch.device) -> str:
     if cfg.backend != "auto":
         return cfg.backend
-    return "native" if device.type == "cuda" else "torch"
+    # the native engine is bf16-compute / fp32-master; an all-fp32 run uses the stock modules
+    if device.type == "cuda" and cfg.dtype != "fp32":
+        return "native"
+    return "torch"
 
 
 def make_backend(cfg: TrainConfig, device: torch.device, comm: Optional[Communicator]):
