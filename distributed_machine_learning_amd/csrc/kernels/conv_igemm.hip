@@ -232,43 +232,66 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
     const int a_row_byte = (wm * WTM + l15) * 128;             // pixel tile (MFMA B operand)
     const int b_row_byte = (BM + wn * WTN + l15) * 128;        // weight tile (MFMA A operand)
 
-    auto compute = [&](int stage) {
+    auto load_frags = [&](int stage, int kk, bf16x8 (&wf)[TN], bf16x8 (&xf)[TM]) {
         const char* base = smem + stage * STAGE_BYTES;
+        const int koff = kk ? koff1 : koff0;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int koff = kk ? koff1 : koff0;
-            bf16x8 wf[TN], xf[TM];
+        for (int i = 0; i < TN; ++i)
+            wf[i] = *(const bf16x8*)(base + b_row_byte + i * 16 * 128 + koff);
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
-                wf[i] = *(const bf16x8*)(base + b_row_byte + i * 16 * 128 + koff);
+        for (int j = 0; j < TM; ++j)
+            xf[j] = *(const bf16x8*)(base + a_row_byte + j * 16 * 128 + koff);
+    };
+    auto mma = [&](const bf16x8 (&wf)[TN], const bf16x8 (&xf)[TM]) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                xf[j] = *(const bf16x8*)(base + a_row_byte + j * 16 * 128 + koff);
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j],
-                                                                        0, 0, 0);
-        }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     };
-
-    // Pipeline: the loads of steps s+1 .. s+D-1 stay in flight across the barrier while step
-    // s is multiplied (counted vmcnt, raw s_barrier).  Iteration s: wait until this wave's
-    // loads of step s have landed, barrier (everyone's have, and everyone is done reading
-    // the stage of step s-1), refill that stage with step s+D, then the MFMAs of step s.
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < steps) issue(s);
-    for (int s = 0; s < steps; ++s) {
+    auto wait_step = [&](int s) {       // this wave's loads of step s have landed
         const int ahead = min(D - 1, steps - 1 - s);
         if (ahead >= 2) wait_vmcnt<2 * LPS>();
         else if (ahead == 1) wait_vmcnt<LPS>();
         else wait_vmcnt<0>();
+    };
+
+    // Pipeline.  Global -> LDS: the loads of steps s+1 .. s+D-1 stay in flight across the
+    // barrier while step s is multiplied (counted vmcnt, raw s_barrier).  LDS -> registers:
+    // a K step is two 32-wide halves; the fragments of the second half are requested before the
+    // MFMAs of the first, and the fragments of the NEXT step's first half right after the
+    // barrier, before the MFMAs of this step's second half - so every LDS round trip hides
+    // behind matrix work instead of following the barrier, where all waves would wait for it
+    // together.  Before the barrier a wave drains its LDS reads (lgkmcnt(0)): the stage it
+    // just read is the one the loads issued after the barrier refill.
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < steps) issue(s);
+    if (steps > 0) {
+        bf16x8 wfa[TN], xfa[TM], wfb[TN], xfb[TM];
+        wait_step(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + D < steps) issue(s + D);
-        compute(s % NS);
+        if (D < steps) issue(D);
+        load_frags(0, 0, wfa, xfa);
+        // (the last step is peeled: with a conditional barrier half inside the loop, the
+        // compiler's wait-count bookkeeping merges both paths and makes the second-half MFMAs
+        // wait for the reads issued after the barrier)
+        for (int s = 0; s + 1 < steps; ++s) {
+            load_frags(s % NS, 1, wfb, xfb);
+            mma(wfa, xfa);
+            // lgkmcnt(0), vmcnt / expcnt untouched: the stage just read is refilled below
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            wait_step(s + 1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + 1 + D < steps) issue(s + 1 + D);
+            load_frags((s + 1) % NS, 0, wfa, xfa);
+            mma(wfb, xfb);
+        }
+        load_frags((steps - 1) % NS, 1, wfb, xfb);
+        mma(wfa, xfa);
+        mma(wfb, xfb);
     }
 
     // ---- BatchNorm statistics for free: column sums (and sums of squares) of this tile's
