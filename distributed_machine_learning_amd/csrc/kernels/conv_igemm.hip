@@ -132,8 +132,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
 
-    const int tile_n = blockIdx.x % p.tiles_n;
-    const int tile_m = blockIdx.x / p.tiles_n;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Renumber so that
+    // an XCD works on a contiguous range of tiles: the tile_n blocks of one pixel tile (same
+    // input lines) and neighbouring pixel tiles (shared halo lines) then hit the same L2.
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int tile_n = bid % p.tiles_n;
+    const int tile_m = bid / p.tiles_n;
     const int n0 = tile_n * BN;
     const int C = p.C, hw = p.hw;
     // NHWC tiling: rows m0.. are consecutive pixels.  PM tiling: row r is image img0 + r at
@@ -578,7 +583,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(IgemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+    int bid = blockIdx.x;       // XCD-contiguous tile ranges, as in the streaming kernel
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int C = p.C, hw = p.hw;
     const int chunks = 1 << p.log_chunks;

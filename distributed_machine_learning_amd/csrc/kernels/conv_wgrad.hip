@@ -78,7 +78,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wco = wave & 1, wci = wave >> 1;
 
-    int t = blockIdx.x;
+    // Workgroups go round-robin to the 8 XCDs (own L2 each) in launch order.  Renumber so
+    // that an XCD owns a contiguous range of pixel splits for ALL tiles: the dy / x pixels of a
+    // split are then fetched into one L2 instead of eight.
+    int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int nblk = gridDim.x * gridDim.y;
+    if ((nblk & 7) == 0) lin = (lin & 7) * (nblk >> 3) + (lin >> 3);
+    const int split = lin / gridDim.x;
+    int t = lin - split * gridDim.x;
     const int tile_ci = t % p.tiles_ci; t /= p.tiles_ci;
     const int tile_co = t % p.tiles_co; t /= p.tiles_co;
     const int tap = t;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
     const int hw = p.hw;
 
     const int total_steps = (p.M + 63) / 64;
-    const int s_begin = blockIdx.y * p.steps_per_split;
+    const int s_begin = split * p.steps_per_split;
     const int s_end = min(total_steps, s_begin + p.steps_per_split);
 
     const int a_c = tid % A_CH, a_r = tid / A_CH;       // dy staging ownership
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float* dst = p.dw + blockIdx.y * p.split_stride + ((size_t)co * 9 + tap) * p.Cin + ci;
+                float* dst = p.dw + split * p.split_stride + ((size_t)co * 9 + tap) * p.Cin + ci;
                 if (p.atomic) atomicAdd(dst, acc[i][j][r]);
                 else *dst = acc[i][j][r];
             }
