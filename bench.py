@@ -127,6 +127,13 @@ def main():
             comm.barrier()
         torch.cuda.synchronize()
 
+    # RCCL builds its channels on first use of each collective: do that outside any timed or
+    # counted step (the gradient buffer is still all zeros here)
+    if comm is not None and hasattr(backend, "comm_only_step"):
+        for _ in range(2):
+            backend.comm_only_step()
+        barrier()
+
     loss = None
     for i in range(ns.warmup):
         loss = backend.train_step(*batches[i % len(batches)])
