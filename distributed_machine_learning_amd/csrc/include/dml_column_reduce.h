@@ -22,12 +22,12 @@ struct ColReducePlan {
     int blocks, rows_per_block;
 };
 
-// About 4 rows per thread - all of a thread's loads in flight at once, these kernels are
-// latency-bound on every layer but the first - at most 512 blocks (two per CU), slab
+// Two rows per thread where the caps below allow - all of a thread's loads in flight at once,
+// these kernels are latency-bound on every layer but the first - at most 512 blocks (two per CU), slab
 // (blocks * 2c floats) within 512 KiB, rows_per_block a multiple of the row lanes of a block.
 inline ColReducePlan plan_col_reduce(int rows, int c) {
     const int lanes = 256 / (c / 8);
-    long long want = (rows + lanes * 4 - 1) / (lanes * 4);
+    long long want = (rows + lanes * 2 - 1) / (lanes * 2);
     if (want < 1) want = 1;
     if (want > 512) want = 512;
     const int cap = kColReduceSlabFloats / (2 * c);

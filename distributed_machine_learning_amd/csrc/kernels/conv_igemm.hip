@@ -453,10 +453,11 @@ int ilog2(int v) {
     return l;
 }
 
-// rows of `stats` the split path's finishing kernel writes: blocks of ~32 rows per row lane
+// rows of `stats` the split path's finishing kernel writes: two rows per row lane and block
+// (the layers that split are small - the kernel is latency-bound, so many short blocks)
 ColReducePlan finish_stats_plan(int M, int N) {
     const int lanes = 256 / (N / 8);
-    int rpb = lanes * 8;
+    int rpb = lanes * 2;
     int blocks = (M + rpb - 1) / rpb;
     if (blocks > 512) {
         rpb = ((M + 511) / 512 + lanes - 1) / lanes * lanes;
