@@ -224,6 +224,9 @@ SplitPlan plan_splits(int M, int tiles, int force_splits, bool slab_mode = true)
     const int total_steps = (M + 63) / 64;
     const int target = slab_mode ? 432 : 288;
     int splits = slab_mode ? (target + tiles / 2) / tiles : (target + tiles - 1) / tiles;
+    // a short reduction under tiles that already cover half the chip (the 2x2 layers): the
+    // partial slabs and their sum would cost more than the split saves
+    if (slab_mode && tiles >= 128 && total_steps <= 16) splits = 1;
     const int max_splits = total_steps >= 4 ? total_steps / 4 : 1;
     if (splits > max_splits) splits = max_splits;
     if (force_splits > 0) splits = force_splits < total_steps ? force_splits : total_steps;

@@ -209,7 +209,7 @@ def test_conv3x3_wgrad(batch, cin, cout, hw):
           atol_scale=2e-3)
 
 
-@pytest.mark.parametrize("cin,cout,hw,batch", [(64, 128, 16, 64), (256, 256, 8, 256), (512, 512, 2, 256)])
+@pytest.mark.parametrize("cin,cout,hw,batch", [(64, 128, 16, 64), (256, 256, 8, 256), (512, 512, 4, 256)])
 def test_conv3x3_wgrad_slab_mode_is_deterministic(cin, cout, hw, batch):
     """Per-split partial results + the batched slab sum: same numbers as the atomic path,
     and bit-identical from run to run."""
