@@ -87,8 +87,18 @@ __device__ __forceinline__ void column_fold(FinalFn&& finalize, const float* ws,
     const int col = blockIdx.x * 16 + cl;
     float sa = 0.f, sb = 0.f;
     if (col < c) {
-#pragma unroll 4
-        for (int k = part; k < nb; k += 16) {
+        int k = part;
+        for (; k + 7 * 16 < nb; k += 8 * 16) {        // 16 loads in flight
+            float va[8], vb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                va[q] = ws[(size_t)(k + q * 16) * 2 * c + col];
+                vb[q] = ws[(size_t)(k + q * 16) * 2 * c + c + col];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { sa += va[q]; sb += vb[q]; }
+        }
+        for (; k < nb; k += 16) {
             sa += ws[(size_t)k * 2 * c + col];
             sb += ws[(size_t)k * 2 * c + c + col];
         }
