@@ -159,6 +159,15 @@ PYBIND11_MODULE(_C, m) {
                          ptr<const float>(srstd), ptr<float>(dgamma), ptr<float>(dbeta),
                          ptr<float>(ws), batch, hw, c, st(s));
     });
+    m.def("fc_train", [](uintptr_t x, uintptr_t w, uintptr_t b, uintptr_t target, uintptr_t logits,
+                         uintptr_t loss, uintptr_t correct, uintptr_t dx, uintptr_t dw, uintptr_t db,
+                         uintptr_t ws, int batch, int in_f, int out_f, uintptr_t s) {
+        fc_train(ptr<const bf16_raw>(x), ptr<const float>(w), ptr<const float>(b),
+                 ptr<const int64_t>(target), ptr<float>(logits), ptr<float>(loss),
+                 ptr<int32_t>(correct), ptr<bf16_raw>(dx), ptr<float>(dw), ptr<float>(db),
+                 ptr<float>(ws), batch, in_f, out_f, st(s));
+    });
+    m.def("fc_train_workspace_elems", &fc_train_workspace_elems);
     m.def("linear_fwd", [](uintptr_t x, uintptr_t w, uintptr_t b, uintptr_t logits, int batch,
                            int in_f, int out_f, uintptr_t s) {
         linear_fwd(ptr<const bf16_raw>(x), ptr<const float>(w), ptr<const float>(b),

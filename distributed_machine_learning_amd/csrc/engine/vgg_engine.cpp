@@ -1,12 +1,12 @@
 // VggEngine: layout planning and the per-step kernel schedule.
 //
 // Schedule of one training step (reference order, /root/reference/part1/main.py:38-46):
-//   memset(grads), memset(loss)                                     optimizer.zero_grad()
-//   conv -> [bn+relu] -> [pool] ... -> linear                       model(data)
-//   softmax cross-entropy fwd+bwd                                   criterion / backward
-//   linear bwd, then per conv layer back to front:
+//   (nothing to zero: every gradient is overwritten)                optimizer.zero_grad()
+//   conv (+ BN statistics) -> [bn+relu(+pool)] | [pool] ...         model(data)
+//   classifier + softmax cross-entropy, forward and backward        criterion / backward
+//   then per conv layer back to front:
 //     [pool bwd] -> [bn+relu bwd] -> bias grad -> wgrad -> dgrad    loss.backward()
-//     -> reducer.bucket_ready(...) for every bucket this layer completes
+//     -> partial-slab sums + reducer.bucket_ready(...) for every bucket this layer completes
 //   reducer.wait_all -> fused SGD -> weight shadow / repack          optimizer.step()
 #include "dml_engine.h"
 
@@ -149,6 +149,7 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         slab_elems_ = need_c1 > slab_elems_ ? need_c1 : slab_elems_;
     }
     slab_off_ = w; w = align_up(w + slab_elems_);
+    fc_ws_off_ = w; w = align_up(w + fc_train_workspace_elems(max_batch_, fc_in_, num_classes_));
     // BatchNorm statistics partials written by the conv epilogues: rows x [2][cout]
     cstats_off_ = w;
     if (bn_) {
@@ -310,21 +311,23 @@ void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t
             in = arena_ + c.pool_off;
         }
     }
-    linear_fwd(in, params_ + fcw_off_, params_ + fcb_off_, ws_ + logits_off_, batch, fc_in_,
-               num_classes_, stream);
+    // in training the classifier runs fused with the loss and its backward (see backward())
+    if (!training)
+        linear_fwd(in, params_ + fcw_off_, params_ + fcb_off_, ws_ + logits_off_, batch, fc_in_,
+                   num_classes_, stream);
     if (training && bn_) ++bn_steps_;
 }
 
 void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hipStream_t stream) {
     const int nconv = (int)convs_.size();
     float* slab = ws_ + slab_off_;
-    softmax_xent(ws_ + logits_off_, target, ws_ + loss_off_, ws_ + dlogits_off_, nullptr, batch,
-                 num_classes_, 1.0f, stream);
     const Conv& last = convs_[nconv - 1];
     const uint16_t* fc_in = arena_ + (last.pool_after ? last.pool_off : last.out_off);
     int cur = 0;        // index of the ping-pong buffer holding the incoming gradient
-    linear_bwd(fc_in, params_ + fcw_off_, ws_ + dlogits_off_, grads_ + fcw_off_, grads_ + fcb_off_,
-               arena_ + gbuf_off_[cur], batch, fc_in_, num_classes_, stream);
+    // classifier + loss, forward and backward, in two launches; every output is overwritten
+    fc_train(fc_in, params_ + fcw_off_, params_ + fcb_off_, target, ws_ + logits_off_,
+             ws_ + loss_off_, nullptr, arena_ + gbuf_off_[cur], grads_ + fcw_off_, grads_ + fcb_off_,
+             ws_ + fc_ws_off_, batch, fc_in_, num_classes_, stream);
     fire_buckets(nconv, stream);
     for (int i = nconv - 1; i >= 0; --i) {
         const Conv& c = convs_[i];
@@ -360,7 +363,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             ConvShape s = {batch, c.hw, c.cin, c.cout};
             // Conv bias gradient.  Under BatchNorm it is exactly zero in exact arithmetic (the
             // normalisation removes any per-channel offset; a framework's value there is
-            // rounding noise), so it is left at the zero the gradient memset wrote.
+            // rounding noise), so it is left at the zero the buffer was allocated with.
             if (!bn_) column_sum(g, grads_ + c.b_off, rows, c.cout, ws_ + stats_off_, stream);
             conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream, 0, ws_ + c.wslab_off);
             const int splits = conv3x3_wgrad_splits(s);
@@ -388,12 +391,8 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
 void VggEngine::forward_backward(const uint16_t* x, const int64_t* target, int batch,
                                  hipStream_t stream) {
     if (!params_) throw std::logic_error("VggEngine: bind() first");
-    // Only the classifier's gradients are accumulated with atomics and need a zero start;
-    // everything else is overwritten (conv biases under BatchNorm are never written and keep
-    // the zero they were allocated with).
-    check_hip(hipMemsetAsync(grads_ + fcw_off_, 0, (param_elems_ - fcw_off_) * sizeof(float), stream),
-              "memset(fc grads)");
-    check_hip(hipMemsetAsync(ws_ + loss_off_, 0, sizeof(float), stream), "memset(loss)");
+    // Nothing to zero: every gradient is overwritten (conv biases under BatchNorm are never
+    // written and keep the zero they were allocated with).
     if (reducer_) {
         reducer_->begin_step();
         reducer_->apply_buffers(stream);        // running statistics := rank 0's

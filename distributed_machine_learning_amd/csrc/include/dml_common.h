@@ -77,6 +77,16 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Wave-wide sum without LDS traffic: DPP inside each 16-lane row, then the four row totals
+// through scalar lane reads (the result is wave-uniform).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    const int r = __builtin_bit_cast(int, row16_sum(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

@@ -114,7 +114,7 @@ class VggEngine {
     size_t param_elems_ = 0, bn_elems_ = 0, arena_elems_ = 0, ws_elems_ = 0;
     size_t shadow_off_ = 0, w1_off_ = 0, gbuf_off_[2] = {0, 0};
     size_t logits_off_ = 0, dlogits_off_ = 0, loss_off_ = 0, stats_off_ = 0, slab_off_ = 0,
-           cstats_off_ = 0;
+           cstats_off_ = 0, fc_ws_off_ = 0;
     SlabSumJobs wgrad_sums_;      // partial-result reductions not yet launched
     size_t slab_elems_ = 0;
     std::vector<SlotInfo> slots_, bn_slots_;

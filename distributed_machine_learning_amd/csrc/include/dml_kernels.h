@@ -166,6 +166,15 @@ void linear_bwd(const bf16_raw* x, const float* w, const float* dlogits, float* 
 void softmax_xent(const float* logits, const int64_t* target, float* loss_sum, float* dlogits,
                   int32_t* correct, int batch, int classes, float grad_scale, hipStream_t stream);
 
+// One training step of the classifier head in two launches: logits = x w^T + b, mean
+// cross-entropy `loss[0]`, top-1 count `correct[0]` (may be null), dx = dlogits w,
+// dw = dlogits^T x, db = sum dlogits - all overwritten, no atomics (bit-reproducible).
+// in_features must be 512, out_features <= 16; `ws` holds fc_train_workspace_elems floats.
+void fc_train(const bf16_raw* x, const float* w, const float* bias, const int64_t* target,
+              float* logits, float* loss, int32_t* correct, bf16_raw* dx, float* dw, float* db,
+              float* ws, int batch, int in_features, int out_features, hipStream_t stream);
+size_t fc_train_workspace_elems(int batch, int in_features, int out_features);
+
 // ---------------------------------------------------------------- optimiser
 // g' = g * grad_scale + wd * p;  m = first ? g' : mu * m + g';  p -= lr * m.
 // Also writes the bf16 shadow copy of p when `shadow` is non-null.

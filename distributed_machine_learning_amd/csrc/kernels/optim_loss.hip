@@ -259,4 +259,182 @@ void softmax_xent(const float* logits, const int64_t* target, float* loss_sum, f
                        grad_scale);
 }
 
+
+// ------------------------------------------------ fused classifier step for training
+// nn.Linear(512, 10) + nn.CrossEntropyLoss forward and backward in two launches
+// (/root/reference/part1/model.py:40,45 and /root/reference/part1/main.py:43-44): the first
+// kernel gives every wave a few rows - logits, softmax, loss, dlogits, dx and the partial
+// dW / db, all from one 16-byte load of the row per lane; a block folds its four waves in
+// LDS - the second sums the per-block partials.  No atomics, no memsets: the result is bit-reproducible.
+constexpr int kFcMaxClasses = 16;
+constexpr int kFcRowsPerWave = 2;
+constexpr int kFcRowsPerBlock = 4 * kFcRowsPerWave;
+
+__global__ __launch_bounds__(256) void fc_train_kernel(
+    const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const int64_t* __restrict__ target, float* __restrict__ logits, uint16_t* __restrict__ dx,
+    float* __restrict__ part, int batch, int k_dim, int n, float inv_batch) {
+    __shared__ float red[kFcMaxClasses * 512 + 4 * (kFcMaxClasses + 2)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t pstride = (size_t)n * k_dim + 2 * kFcMaxClasses;
+    float* my = part + (size_t)blockIdx.x * pstride;
+    const int kb = lane * 8;                 // k_dim == 512: one 16-byte chunk per lane
+    float loss_acc = 0.f, ok_acc = 0.f, db_acc = 0.f;      // lane c < n accumulates db[c]
+    // every global load of the wave is issued up front: its rows, their targets, the weights
+    uint4 xraw[kFcRowsPerWave];
+    int tgt[kFcRowsPerWave];
+#pragma unroll
+    for (int rr = 0; rr < kFcRowsPerWave; ++rr) {
+        const int row = (blockIdx.x * 4 + wave) * kFcRowsPerWave + rr;
+        const int rc = row < batch ? row : batch - 1;
+        xraw[rr] = *(const uint4*)(x + (size_t)rc * k_dim + kb);
+        tgt[rr] = (int)target[rc];
+    }
+    float wreg[kFcMaxClasses][8], dwacc[kFcMaxClasses][8];
+#pragma unroll
+    for (int c = 0; c < kFcMaxClasses; ++c) {
+        if (c < n) {
+            const float4 a = *(const float4*)(w + (size_t)c * k_dim + kb);
+            const float4 b = *(const float4*)(w + (size_t)c * k_dim + kb + 4);
+            wreg[c][0] = a.x; wreg[c][1] = a.y; wreg[c][2] = a.z; wreg[c][3] = a.w;
+            wreg[c][4] = b.x; wreg[c][5] = b.y; wreg[c][6] = b.z; wreg[c][7] = b.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dwacc[c][i] = 0.f;
+    }
+#pragma unroll
+    for (int rr = 0; rr < kFcRowsPerWave; ++rr) {
+        const int row = (blockIdx.x * 4 + wave) * kFcRowsPerWave + rr;
+        if (row >= batch) break;
+        float xv[8];
+        unpack8(xraw[rr], xv);
+        const int t = tgt[rr];
+        float lg[kFcMaxClasses];
+        float mx = -3.0e38f;
+        int arg = 0;
+#pragma unroll
+        for (int c = 0; c < kFcMaxClasses; ++c) {
+            lg[c] = 0.f;
+            if (c < n) {
+                float p = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) p += xv[i] * wreg[c][i];
+                lg[c] = wave_sum_dpp(p) + bias[c];
+                if (lg[c] > mx) { mx = lg[c]; arg = c; }
+            }
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < kFcMaxClasses; ++c)
+            if (c < n) se += __expf(lg[c] - mx);
+        const float inv = 1.f / se;
+        float lt = 0.f, o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < kFcMaxClasses; ++c) {
+            if (c < n) {
+                if (c == t) lt = lg[c];
+                const float dl = (__expf(lg[c] - mx) * inv - (c == t ? 1.f : 0.f)) * inv_batch;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    o[i] += dl * wreg[c][i];
+                    dwacc[c][i] += dl * xv[i];
+                }
+                if (lane == c) {
+                    logits[(size_t)row * n + c] = lg[c];
+                    db_acc += dl;
+                }
+            }
+        }
+        loss_acc += (mx + __logf(se) - lt) * inv_batch;
+        ok_acc += (arg == t) ? 1.f : 0.f;
+        if (dx) *(uint4*)(dx + (size_t)row * k_dim + kb) = pack8(o);
+    }
+    // block partial: the four waves add their dW into LDS one after the other
+    float* tails = red + kFcMaxClasses * 512;
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int c = 0; c < kFcMaxClasses; ++c) {
+                if (c < n) {
+                    float4* dst = (float4*)(red + c * 512 + kb);
+                    float4 a = {dwacc[c][0], dwacc[c][1], dwacc[c][2], dwacc[c][3]};
+                    float4 b = {dwacc[c][4], dwacc[c][5], dwacc[c][6], dwacc[c][7]};
+                    if (turn > 0) {
+                        const float4 pa = dst[0], pb = dst[1];
+                        a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+                        b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+                    }
+                    dst[0] = a;
+                    dst[1] = b;
+                }
+            }
+            if (lane < kFcMaxClasses) tails[wave * (kFcMaxClasses + 2) + lane] = lane < n ? db_acc : 0.f;
+            if (lane == 0) {
+                tails[wave * (kFcMaxClasses + 2) + kFcMaxClasses] = loss_acc;
+                tails[wave * (kFcMaxClasses + 2) + kFcMaxClasses + 1] = ok_acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n * 512 / 4; i += 256)
+        ((float4*)my)[i] = ((const float4*)red)[i];
+    if (threadIdx.x < kFcMaxClasses + 2) {
+        const int q = threadIdx.x;
+        const float v = tails[q] + tails[(kFcMaxClasses + 2) + q] + tails[2 * (kFcMaxClasses + 2) + q] +
+                        tails[3 * (kFcMaxClasses + 2) + q];
+        my[(size_t)n * k_dim + (q < kFcMaxClasses ? q : q)] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void fc_train_finish_kernel(
+    const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+    float* __restrict__ loss, int32_t* __restrict__ correct, int parts, int k_dim, int n) {
+    const size_t pstride = (size_t)n * k_dim + 2 * kFcMaxClasses;
+    const int total = n * k_dim;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        float s = 0.f;
+        int q = 0;
+        for (; q + 7 < parts; q += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(q + u) * pstride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; q < parts; ++q) s += part[(size_t)q * pstride + i];
+        dw[i] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < kFcMaxClasses + 2) {
+        float s = 0.f;
+        for (int q = 0; q < parts; ++q) s += part[(size_t)q * pstride + total + threadIdx.x];
+        if (threadIdx.x < n) db[threadIdx.x] = s;
+        else if (threadIdx.x == kFcMaxClasses) loss[0] = s;
+        else if (threadIdx.x == kFcMaxClasses + 1 && correct) correct[0] = (int)(s + 0.5f);
+    }
+}
+
+size_t fc_train_workspace_elems(int batch, int in_features, int out_features) {
+    const int blocks = (batch + kFcRowsPerBlock - 1) / kFcRowsPerBlock;
+    return (size_t)blocks * ((size_t)out_features * in_features + 2 * kFcMaxClasses);
+}
+
+void fc_train(const bf16_raw* x, const float* w, const float* bias, const int64_t* target,
+              float* logits, float* loss, int32_t* correct, bf16_raw* dx, float* dw, float* db,
+              float* ws, int batch, int in_features, int out_features, hipStream_t stream) {
+    if (in_features != 512)
+        throw std::invalid_argument("fc_train: the fused classifier step handles 512 input features");
+    if (out_features < 1 || out_features > kFcMaxClasses)
+        throw std::invalid_argument("fc_train: 1..16 classes");
+    if (batch <= 0) return;
+    const int blocks = (batch + kFcRowsPerBlock - 1) / kFcRowsPerBlock;
+    hipLaunchKernelGGL(fc_train_kernel, dim3(blocks), dim3(256), 0, stream, x, w, bias, target,
+                       logits, dx, ws, batch, in_features, out_features, 1.0f / (float)batch);
+    const int total = out_features * in_features;
+    hipLaunchKernelGGL(fc_train_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
+                       (const float*)ws, dw, db, loss, correct, blocks, in_features, out_features);
+}
+
 }  // namespace dml

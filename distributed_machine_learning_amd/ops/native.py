@@ -353,6 +353,28 @@ def softmax_xent(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = T
     return loss, dl, correct
 
 
+def fc_train(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, target: torch.Tensor):
+    """Fused classifier training step.  Returns ``(logits, loss[1], correct[1], dx, dw, db)``."""
+    _req(x, torch.bfloat16, "x", 2)
+    _req(w, torch.float32, "w", 2)
+    _req(bias, torch.float32, "bias", 1)
+    _req(target, torch.int64, "target", 1)
+    b, k = x.shape
+    n = w.shape[0]
+    dev = x.device
+    logits = torch.empty(b, n, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    correct = torch.empty(1, dtype=torch.int32, device=dev)
+    dx = torch.empty(b, k, dtype=torch.bfloat16, device=dev)
+    dw = torch.empty(n, k, dtype=torch.float32, device=dev)
+    db = torch.empty(n, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib().fc_train_workspace_elems(b, k, n), dtype=torch.float32, device=dev)
+    lib().fc_train(x.data_ptr(), w.data_ptr(), bias.data_ptr(), target.data_ptr(), logits.data_ptr(),
+                   loss.data_ptr(), correct.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                   ws.data_ptr(), b, k, n, _stream())
+    return logits, loss, correct, dx, dw, db
+
+
 # ---------------------------------------------------------------------- optimiser
 def sgd_momentum_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, momentum: float,
                   weight_decay: float, grad_scale: float = 1.0,

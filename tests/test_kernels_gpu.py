@@ -414,3 +414,28 @@ def test_augment_kernel_matches_reference_transform():
                           rtol=1e-2, atol=1e-2)
     x = torch.randn(4, 3, 32, 32, device=DEV)
     assert torch.equal(n.nchw_to_nhwc4(x)[..., :3], x.permute(0, 2, 3, 1).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("batch", [3, 64, 256])
+def test_fc_train_fused(batch):
+    """Classifier head: logits, loss, top-1 count and all three gradients in two launches."""
+    n = native()
+    x = rand_bf16(batch, 512, seed=81)
+    w = (torch.randn(10, 512, device=DEV) * 0.05)
+    b = torch.randn(10, device=DEV) * 0.1
+    t = torch.randint(0, 10, (batch,), device=DEV)
+    logits, loss, correct, dx, dw, db = n.fc_train(x, w, b, t)
+    xr = x.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref_logits = F.linear(xr, wr, br)
+    ref_loss = F.cross_entropy(ref_logits, t)
+    ref_loss.backward()
+    check("fc logits", logits, ref_logits.detach(), rtol=1e-4, atol_scale=1e-4)
+    assert abs(float(loss) - float(ref_loss)) < 1e-4
+    assert int(correct) == int((ref_logits.argmax(1) == t).sum())
+    check("fc dx", dx, xr.grad)
+    check("fc dw", dw, wr.grad, rtol=1e-3, atol_scale=1e-3)
+    check("fc db", db, br.grad, rtol=1e-3, atol_scale=1e-3)
+    again = n.fc_train(x, w, b, t)
+    assert torch.equal(again[4], dw) and torch.equal(again[1], loss)     # bit-reproducible
