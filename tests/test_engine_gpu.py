@@ -270,9 +270,9 @@ def test_sync_modes_world1_match_no_sync(sync):
             _, x4, t = _batch(32, seed=step)
             la = float(base.train_step(x4, t).item())
             lb = float(nb.train_step(x4, t).item())
-            assert abs(la - lb) < 1e-3
+            assert la == lb
         comm.guard_sync(30)
-        assert _rel(nb.params, base.params) < 1e-3
+        assert torch.equal(nb.params, base.params)
         nb.close()
     finally:
         comm.destroy()
@@ -281,7 +281,8 @@ def test_sync_modes_world1_match_no_sync(sync):
 def test_ddp_overlap_matches_serialized_streams():
     """Race check for the side-stream choreography (bucket events, overlapped running-stat
     broadcast, optimizer wait): the overlapped run must reproduce the debug mode that issues
-    every collective in line on the compute stream."""
+    every collective in line on the compute stream - bit for bit, and both must equal the run
+    without any communicator."""
     from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
     comm = RcclCommunicator("127.0.0.1:29611", 0, 1, 0, timeout_s=60)
     try:
@@ -289,24 +290,40 @@ def test_ddp_overlap_matches_serialized_streams():
         slow, _ = _mk(True, sync="ddp", comm=comm, bucket_cap_mb=1.0, serialize_streams=True)
         base, _ = _mk(True)
         assert fast.reducer.num_buckets >= 6
-        for step in range(3):
+        for step in range(4):
             _, x4, t = _batch(32, seed=step)
-            la = float(fast.train_step(x4, t).item())
-            lb = float(slow.train_step(x4, t).item())
-            lc = float(base.train_step(x4, t).item())
-            # Not bitwise: wgrad accumulates with float atomics, and a last-bit difference can
-            # flip the bf16 rounding of an activation, so even two identical engines drift
-            # apart by ~1e-3 in loss per step.
-            assert abs(la - lb) < 2e-2 and abs(la - lc) < 2e-2, (step, la, lb, lc)
+            la = fast.train_step(x4, t).clone()
+            lb = slow.train_step(x4, t).clone()
+            lc = base.train_step(x4, t).clone()
+            # the training step is free of atomics, so any difference is an ordering bug
+            assert torch.equal(la, lb) and torch.equal(la, lc), (step, float(la), float(lb), float(lc))
         comm.guard_sync(30)
-        assert _rel(fast.params, slow.params) < 2e-2
-        assert _rel(fast.params, base.params) < 2e-2
-        assert _rel(fast.bn_buffers, base.bn_buffers) < 2e-2
-        assert _rel(slow.bn_buffers, base.bn_buffers) < 2e-2
+        assert torch.equal(fast.params, slow.params)
+        assert torch.equal(fast.params, base.params)
+        assert torch.equal(fast.bn_buffers, base.bn_buffers)
+        assert torch.equal(slow.bn_buffers, base.bn_buffers)
         fast.close()
         slow.close()
     finally:
         comm.destroy()
+
+
+@pytest.mark.parametrize("batch_norm", [False, True])
+def test_training_is_bit_reproducible(batch_norm):
+    """No kernel of the training step accumulates with atomics (wgrad sums per-split slabs,
+    the reductions fold partial rows, the classifier sums per-block partials), so two engines
+    fed the same batches must agree bit for bit."""
+    a, _ = _mk(batch_norm, batch=64)
+    b, _ = _mk(batch_norm, batch=64)
+    for step in range(3):
+        _, x4, t = _batch(64, seed=step)
+        la = a.train_step(x4, t).clone()
+        lb = b.train_step(x4, t).clone()
+        assert torch.equal(la, lb), (step, float(la), float(lb))
+    assert torch.equal(a.params, b.params)
+    assert torch.equal(a.momentum, b.momentum)
+    if batch_norm:
+        assert torch.equal(a.bn_buffers, b.bn_buffers)
 
 
 def test_graph_replay_matches_eager():
@@ -316,9 +333,9 @@ def test_graph_replay_matches_eager():
         _, x4, t = _batch(32, seed=step)
         la = float(eager.train_step(x4, t).item())
         lb = float(graph.train_step(x4, t).item())
-        assert abs(la - lb) < 1e-3, (step, la, lb)
+        assert la == lb, (step, la, lb)
     assert graph.engine.has_graph
-    assert _rel(graph.params, eager.params) < 1e-3
+    assert torch.equal(graph.params, eager.params)
 
 
 def test_cli_on_gpu_prints_reference_lines(capsys):
