@@ -48,13 +48,14 @@ def parse():
     ap.add_argument("--backend", choices=("native", "torch"), default="native")
     ap.add_argument("--dtype", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU)")
-    ap.add_argument("--bucket-cap-mb", type=float, default=12.0,
-                    help="gradient bucket size.  12 MiB (first bucket included) cuts VGG-11's "
-                         "37 MB of gradients into {fc1, conv8, conv7}, {conv6, conv5} and "
-                         "{conv4..conv1}: two large all-reduces that start in the first half of "
-                         "backward and a 3.9 MB tail; every extra bucket costs a cross-stream "
-                         "event hand-off on a ~1 ms step.  The reference's 25 MB would leave a "
-                         "27 MB bucket that only completes with the last wgrad")
+    ap.add_argument("--bucket-cap-mb", type=float, default=24.0,
+                    help="gradient bucket size.  24 MiB (first bucket included) cuts VGG-11's "
+                         "37 MB of gradients into {fc1, conv8, conv7, conv6} - ready a third of "
+                         "the way into backward - and {conv5 .. conv1}, which --tail-bucket-cap-mb "
+                         "splits again.  Every bucket costs ~13 us of compute-stream time in "
+                         "cross-stream hand-offs (measured at one rank: ~3 us for the event "
+                         "record, ~10 us for the second queue's wait / record), so few large "
+                         "buckets beat many small ones on a ~0.8 ms step")
     ap.add_argument("--first-bucket-cap-mb", type=float, default=None,
                     help="defaults to --bucket-cap-mb")
     ap.add_argument("--tail-bucket-cap-mb", type=float, default=1.0,
