@@ -69,7 +69,6 @@ BucketReducer::BucketReducer(RcclComm* comm, float* flat_grads, std::vector<Slic
 BucketReducer::~BucketReducer() {
     for (auto e : ready_) (void)hipEventDestroy(e);
     for (auto e : done_) (void)hipEventDestroy(e);
-    if (buffers_done_) (void)hipEventDestroy(buffers_done_);
     if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
 }
 
@@ -92,12 +91,6 @@ void BucketReducer::bucket_ready(int b, hipStream_t compute) {
     check_hip(hipStreamWaitEvent(comm_stream_, ready_[b], 0), "hipStreamWaitEvent(comm)");
     comm_->all_reduce(grads_ + s.offset, s.count, DT_F32, average_, comm_stream_);
     check_hip(hipEventRecord(done_[b], comm_stream_), "hipEventRecord(done)");
-    if (buffers_to_send_) {
-        buffers_to_send_ = false;
-        comm_->broadcast(buffers_, buffers_shadow_, buffers_count_, DT_F32, 0, comm_stream_);
-        check_hip(hipEventRecord(buffers_done_, comm_stream_), "hipEventRecord(buffers done)");
-        buffers_pending_ = true;
-    }
 }
 
 void BucketReducer::wait_all(hipStream_t compute) {
@@ -109,37 +102,54 @@ void BucketReducer::wait_all(hipStream_t compute) {
     // event of the most recent one covers them all: one cross-stream wait, not one per bucket.
     if (!serialize_ && last_ready_ >= 0)
         check_hip(hipStreamWaitEvent(compute, done_[last_ready_], 0), "hipStreamWaitEvent(compute)");
+    if (buffers_staged_) {
+        buffers_staged_ = false;
+        buffers_pending_ = true;        // the staging area now holds rank 0's values everywhere
+    }
 }
 
-void BucketReducer::set_buffer_sync(float* buffers, float* shadow, size_t count) {
-    if (count && (!buffers || !shadow))
+void BucketReducer::set_buffer_sync(float* buffers, float* staging, size_t count) {
+    if (count && (!buffers || !staging))
         throw std::invalid_argument("BucketReducer: buffer sync needs both pointers");
+    if (count && average_)
+        throw std::invalid_argument("BucketReducer: buffers ride in a SUM all-reduce; fold the "
+                                    "mean into the optimizer's gradient scale");
+    if (count) {
+        // the staging area must be the tail of one bucket's slice
+        bool inside = false;
+        for (const Slice& s : slices_)
+            if (staging >= grads_ + s.offset && staging + count <= grads_ + s.offset + s.count)
+                inside = true;
+        if (!inside)
+            throw std::invalid_argument("BucketReducer: the buffer staging area must lie inside a "
+                                        "bucket slice");
+    }
     buffers_ = buffers;
-    buffers_shadow_ = shadow;
+    buffers_staging_ = staging;
     buffers_count_ = count;
-    buffers_pending_ = buffers_to_send_ = false;
-    if (count && !buffers_done_)
-        check_hip(hipEventCreateWithFlags(&buffers_done_, kEventFlags), "hipEventCreate");
+    buffers_pending_ = buffers_staged_ = false;
 }
 
-void BucketReducer::buffers_updated(hipStream_t) {
-    // Forward is done, so rank 0's statistics are final.  The broadcast itself rides along
-    // with the first bucket of this backward (one event hand-off fewer); in debug mode it
-    // happens in place at the next step's start.
+void BucketReducer::buffers_updated(hipStream_t compute) {
+    // Forward is done, so rank 0's statistics are final.  They travel inside a gradient
+    // bucket: rank 0 copies them into the staging floats that bucket's slice ends with, every
+    // other rank zeroes its copy, and the bucket's SUM all-reduce leaves rank 0's values on
+    // all ranks - no extra collective, no extra event.
     if (!buffers_count_) return;
-    if (serialize_) buffers_pending_ = true;
-    else buffers_to_send_ = true;
+    const size_t bytes = buffers_count_ * sizeof(float);
+    if (comm_->rank() == 0)
+        check_hip(hipMemcpyAsync(buffers_staging_, buffers_, bytes, hipMemcpyDeviceToDevice, compute),
+                  "hipMemcpyAsync(stage buffers)");
+    else
+        check_hip(hipMemsetAsync(buffers_staging_, 0, bytes, compute), "hipMemsetAsync(staging)");
+    buffers_staged_ = true;
 }
 
 void BucketReducer::apply_buffers(hipStream_t compute) {
+    // ordered after the previous step's wait_all on this stream
     if (!buffers_count_ || !buffers_pending_) return;
     buffers_pending_ = false;
-    if (serialize_) {
-        comm_->broadcast(buffers_, buffers_count_, DT_F32, 0, compute);
-        return;
-    }
-    check_hip(hipStreamWaitEvent(compute, buffers_done_, 0), "hipStreamWaitEvent(buffers)");
-    check_hip(hipMemcpyAsync(buffers_, buffers_shadow_, buffers_count_ * sizeof(float),
+    check_hip(hipMemcpyAsync(buffers_, buffers_staging_, buffers_count_ * sizeof(float),
                              hipMemcpyDeviceToDevice, compute),
               "hipMemcpyAsync(buffers)");
 }
@@ -223,8 +233,8 @@ void bind_comm(py::module_& m) {
             r.bucket_ready(b, (hipStream_t)s);
         })
         .def("wait_all", [](BucketReducer& r, uintptr_t s) { r.wait_all((hipStream_t)s); })
-        .def("set_buffer_sync", [](BucketReducer& r, uintptr_t buf, uintptr_t shadow, size_t n) {
-            r.set_buffer_sync((float*)buf, (float*)shadow, n);
+        .def("set_buffer_sync", [](BucketReducer& r, uintptr_t buf, uintptr_t staging, size_t n) {
+            r.set_buffer_sync((float*)buf, (float*)staging, n);
         })
         .def("buffers_updated", [](BucketReducer& r, uintptr_t s) {
             r.buffers_updated((hipStream_t)s);

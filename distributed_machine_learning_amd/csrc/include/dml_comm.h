@@ -111,10 +111,10 @@ std::vector<BucketRange> plan_buckets(const std::vector<size_t>& sizes_bytes, si
 //
 // Module buffers (BatchNorm running statistics) follow rank 0 the way
 // DistributedDataParallel(broadcast_buffers=True) makes them: every forward starts from
-// rank 0's values.  Rank 0's buffers are final once its forward has run, so the broadcast
-// is issued on the communication stream behind the first bucket of the same step, into a
-// shadow copy (hidden under backward), and the next step copies the shadow over the live
-// buffers before its forward.
+// rank 0's values.  Rank 0's buffers are final once its forward has run; they ride inside a
+// gradient bucket (staging floats at the end of that bucket's slice: rank 0's copy there,
+// zeros on every other rank, so the SUM all-reduce delivers rank 0's values) and the next step
+// copies the staging area over the live buffers before its forward.  averaging must be off.
 class BucketReducer {
   public:
     struct Slice { size_t offset, count; };
@@ -127,10 +127,10 @@ class BucketReducer {
     void wait_all(hipStream_t compute);
     hipStream_t comm_stream() const { return comm_stream_; }
 
-    void set_buffer_sync(float* buffers, float* shadow, size_t count);
+    void set_buffer_sync(float* buffers, float* staging, size_t count);
     void buffers_updated(hipStream_t compute);      // call after the forward pass
     void apply_buffers(hipStream_t compute);        // call before the next forward pass
-    void drop_pending_buffers() { buffers_pending_ = buffers_to_send_ = false; }
+    void drop_pending_buffers() { buffers_pending_ = buffers_staged_ = false; }
 
   private:
     RcclComm* comm_;
@@ -142,10 +142,9 @@ class BucketReducer {
     std::vector<char> launched_;
     int last_ready_ = -1;
     float* buffers_ = nullptr;
-    float* buffers_shadow_ = nullptr;
+    float* buffers_staging_ = nullptr;
     size_t buffers_count_ = 0;
-    bool buffers_pending_ = false, buffers_to_send_ = false;
-    hipEvent_t buffers_done_ = nullptr;
+    bool buffers_pending_ = false, buffers_staged_ = false;
 };
 
 void bind_comm(pybind11::module_& m);

@@ -86,10 +86,22 @@ class NativeBackend:
             buckets = C.plan_buckets(sizes, int(cfg.bucket_cap_mb * (1 << 20)),
                                      int(cfg.first_bucket_cap_mb * (1 << 20)))
             buckets = cap_tail_bucket(buckets, sizes, int(cfg.tail_bucket_cap_mb * (1 << 20)))
+            e = self.engine
+            stage = cfg.batch_norm and cfg.broadcast_buffers and e.bn_elems > 0
+            if stage:
+                # room for the BatchNorm buffers behind the last gradient (same storage offsets
+                # for everything the engine addresses)
+                grown = torch.zeros(e.param_elems + e.bn_elems, dtype=torch.float32,
+                                    device=self.device)
+                self.grads = grown
+                e.bind(self.params.data_ptr(), self.grads.data_ptr(), self.momentum.data_ptr(),
+                       self.bn_buffers.data_ptr(), self.arena.data_ptr(), self.workspace.data_ptr())
             slices = []
-            for lo, hi in buckets:
+            for b, (lo, hi) in enumerate(buckets):
                 start = self.slots[lo].offset
                 end = self.slots[hi - 1].offset + self.slots[hi - 1].numel
+                if stage and b == 0:        # the first bucket ends with the last parameter
+                    end = e.param_elems + e.bn_elems
                 slices.append((start, end - start))
             self.buckets = buckets
             self._bucket_slices = slices
@@ -99,12 +111,11 @@ class NativeBackend:
                                            cfg.serialize_streams)
             self._grad_scale = 1.0 / self.world if reduce == "mean" else 1.0
             self.engine.set_reducer(self.reducer, buckets)
-            if cfg.batch_norm and cfg.broadcast_buffers:
-                # DDP's per-forward buffer broadcast, issued by the reducer after each
-                # forward (hidden under backward) and applied before the next one
-                self._bn_shadow = torch.zeros_like(self.bn_buffers)
+            if stage:
+                # DDP's per-forward buffer broadcast: rank 0's running statistics ride in the
+                # staging floats the first bucket's slice ends with (see BucketReducer)
                 self.reducer.set_buffer_sync(self.bn_buffers.data_ptr(),
-                                             self._bn_shadow.data_ptr(), self.engine.bn_elems)
+                                             self.grads[e.param_elems:].data_ptr(), e.bn_elems)
             # what DistributedDataParallel's constructor does: everyone adopts rank 0's state
             if self.world > 1:
                 comm.broadcast(self.params, 0)
