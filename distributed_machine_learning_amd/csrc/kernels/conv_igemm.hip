@@ -170,8 +170,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
     // fetches the 16-byte chunk slot ^ ((row >> 1) & 7) of its row.  Halo taps and rows past
     // M get an out-of-range offset, for which the buffer range check writes zeros.
     const int lrow = lane >> 3, slot = lane & 7;
-    int pix_off[A_IT];       // element offset of (b,h,w,chunk) or -1 when the row is past M
-    int pix_hw[A_IT];        // (h << 16) | w
+    // Per lane only a fixed byte offset and a 9-bit tap mask; everything that changes from
+    // step to step (tap shift, channel chunk) is wave-uniform and travels in the scalar offset
+    // of the buffer load, so a step costs two VALU instructions per load (mask test + select).
+    int pix_voff[A_IT];      // byte offset of (b,h,w, this lane's chunk slot), chunk 0
+    unsigned tapmask[A_IT];  // bit t: tap t of this row reads inside the image (0: row past M)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int r = wave * (BM / NW) + i * 8 + lrow;
@@ -179,8 +182,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
         const bool row_ok = PM ? (img0 + r < p.batch) : (m < p.M);
         const int w_ = m & (hw - 1);
         const int h_ = (m >> p.log_hw) & (hw - 1);
-        pix_hw[i] = (h_ << 16) | w_;
-        pix_off[i] = row_ok ? m * C + ((slot ^ ((r >> 1) & 7)) << 3) : -1;
+        unsigned bits = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
+            if ((unsigned)hh < (unsigned)hw && (unsigned)ww < (unsigned)hw) bits |= 1u << t;
+        }
+        tapmask[i] = row_ok ? bits : 0u;
+        pix_voff[i] = (m * C + ((slot ^ ((r >> 1) & 7)) << 3)) * 2;
     }
     int w_off[B_IT];         // byte offset of (n, tap 0, chunk) in the weight matrix
 #pragma unroll
@@ -188,8 +197,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
         const int r = wave * (BN / NW) + i * 8 + lrow;
         w_off[i] = ((n0 + r) * 9 * C + ((slot ^ ((r >> 1) & 7)) << 3)) * 2;
     }
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    // The pixel descriptor starts (hw + 1) pixels BEFORE the tensor so that the scalar offset
+    // (tap shift + that bias) is never negative; lanes whose tap is padding, or whose row is
+    // past the end, use an offset beyond the descriptor's extent and receive zeros.
+    const int halo_bytes = (hw + 1) * C * 2;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.x - halo_bytes), 0, p.x_bytes + 2 * (unsigned)halo_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
@@ -201,16 +214,13 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
         const int tap = (int)((tap_list >> (4 * issue_ti)) & 15);
         if (++issue_ti == ntaps) { issue_ti = 0; ++issue_cc; }
         const int dh = tap / 3 - 1, dw = tap % 3 - 1;
-        const int shift = (dh * hw + dw) * C + cc * 64;
+        const int xs = ((dh * hw + dw) * C + cc * 64) * 2 + halo_bytes;     // uniform, >= 0
         char* sA = smem + (s % NS) * STAGE_BYTES + wave * (BM / NW) * 128;
         char* sB = smem + (s % NS) * STAGE_BYTES + BM * 128 + wave * (BN / NW) * 128;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int hh = (pix_hw[i] >> 16) + dh, ww = (pix_hw[i] & 0xffff) + dw;
-            const bool ok = pix_off[i] >= 0 && (unsigned)hh < (unsigned)hw &&
-                            (unsigned)ww < (unsigned)hw;
-            const int voff = ok ? (pix_off[i] + shift) * 2 : kOutOfRange;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(sA + i * 1024), 16, voff, 0,
+            const int voff = ((tapmask[i] >> tap) & 1u) ? pix_voff[i] : kOutOfRange;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(sA + i * 1024), 16, voff, xs,
                                                      0, 0);
         }
         const int wshift = (tap * C + cc * 64) * 2;
@@ -218,9 +228,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
         for (int i = 0; i < B_IT; ++i) {
             // (the offset must be a named value: hipcc's host pass rejects the whole kernel
             // template when an expression is passed in this argument position)
-            const int voff = w_off[i] + wshift;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + i * 1024), 16, voff, 0,
-                                                     0, DML_W_AUX);
+            const int voff = w_off[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(sB + i * 1024), 16, voff,
+                                                     wshift, 0, DML_W_AUX);
         }
     };
 
