@@ -53,19 +53,23 @@ def range(name: str, enabled: bool = True):
 
 
 ROCPROF_RECIPES = {
-    # per-kernel time table (copy the *_kernel_stats.csv into profiles/)
-    "kernel_stats": "rocprofv3 --kernel-trace --stats --output-format csv "
-                    "-d gpurun_out/prof_stats -- python3 bench.py --steps 10 --warmup 3",
-    # matrix-core / LDS behaviour, one pass (8 SQ counters at most)
-    "mfma_lds": "rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES "
-                "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 "
-                "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS "
-                "-d gpurun_out/prof_mfma -- python3 bench.py --steps 3 --warmup 1",
-    # HBM read traffic (FETCH_SIZE takes 3 of the 4 TCC slots) and, separately, writes
-    "hbm_read": "rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE "
-                "-d gpurun_out/prof_fetch -- python3 bench.py --steps 3 --warmup 1",
-    "hbm_write": "rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE "
-                 "-d gpurun_out/prof_write -- python3 bench.py --steps 3 --warmup 1",
+    # per-kernel time table: the result database is summarised by tools/rocpd_summary.py
+    # (profiles/part3_*_kernels.txt) and tools/rocpd_gaps.py (idle gaps between kernels)
+    "kernel_stats": "rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bn -o bn -- "
+                    "python3 bench.py --steps 50 --warmup 10",
+    # matrix-core / LDS behaviour of every conv kernel, one pass (8 SQ counters at most);
+    # summarised by tools/rocpd_pmc.py (profiles/conv_kernels_pmc.txt)
+    "mfma_lds": "rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT "
+                "SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE "
+                "-d gpurun_out/pmc1 -o pmc -- python3 tools/pmc_conv.py",
+    # L2 behaviour and MFMA op counts, second pass
+    "l2_mfma_ops": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_sum "
+                   "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_LDS_DATA_FIFO_FULL "
+                   "SQ_LDS_CMD_FIFO_FULL -d gpurun_out/pmc2 -o pmc -- python3 tools/pmc_conv.py",
+    # one kernel, one plan (LAYER / KIND / PLAN in the environment): tools/pmc_one.py
+    "one_kernel": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
+                  "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES "
+                  "GRBM_GUI_ACTIVE -d gpurun_out/pmcA -o a -- python3 tools/pmc_one.py",
 }
 
 
