@@ -154,25 +154,9 @@ def main():
     barrier()
 
     overlap = None
-    if ns.report_overlap and comm is not None and hasattr(backend, "set_comm_enabled"):
-        def timed(fn, n):
-            barrier()
-            t = time.perf_counter()
-            for i in range(n):
-                fn(i)
-            barrier()
-            return (time.perf_counter() - t) / n * 1e3
-        n = max(10, min(ns.steps, 50))
-        full = timed(lambda i: backend.train_step(*batches[i % len(batches)]), n)
-        backend.set_comm_enabled(False)
-        compute = timed(lambda i: backend.train_step(*batches[i % len(batches)]), n)
-        backend.set_comm_enabled(True)
-        comm_ms = timed(lambda i: backend.comm_only_step(), n)
-        exposed = max(full - compute, 0.0)
-        overlap = {"step_ms": round(full, 4), "compute_only_ms": round(compute, 4),
-                   "comm_only_ms": round(comm_ms, 4), "exposed_comm_ms": round(exposed, 4),
-                   "overlap_fraction": round(1.0 - min(exposed / comm_ms, 1.0), 3)
-                   if comm_ms > 0 else None}
+    if ns.report_overlap and comm is not None:
+        from distributed_machine_learning_amd.utils.overlap import measure_comm_split
+        overlap = measure_comm_split(backend, comm, batches, n=max(10, min(ns.steps, 50)))
 
     if comm is not None:       # MAX over ranks
         times = torch.zeros(world, device=device)

@@ -64,6 +64,9 @@ def build_parser(defaults: TrainConfig, distributed_flags: bool = True) -> argpa
     p.add_argument("--comm-timeout", dest="comm_timeout_s", type=float,
                    default=defaults.comm_timeout_s)
     p.add_argument("--profile-ranges", action="store_true", default=defaults.profile_ranges)
+    p.add_argument("--report-overlap", action="store_true", default=defaults.report_overlap,
+                   help="after training: time the step with and without its collectives and "
+                        "the collectives alone; print the exposed time and overlap fraction")
     p.add_argument("--save", dest="checkpoint_out", type=str, default=None)
     p.add_argument("--load", dest="checkpoint_in", type=str, default=None)
     p.add_argument("--threads", type=int, default=defaults.threads)

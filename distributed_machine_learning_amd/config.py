@@ -77,6 +77,7 @@ class TrainConfig:
     announce_epoch: bool = False           # part3/main.py:43
     json: bool = False
     profile_ranges: bool = False
+    report_overlap: bool = False           # after the run: comm/compute split of a step
     checkpoint_out: Optional[str] = None
     checkpoint_in: Optional[str] = None
 

@@ -61,6 +61,21 @@ class TorchBackend:
     def train_mode(self, on: bool = True) -> None:
         self.model.train(on)
 
+    # ------------------------------------------- communication / compute accounting
+    def set_comm_enabled(self, on: bool) -> None:
+        """Detach (or re-attach) every collective of the step; timing aid only, ranks drift
+        apart while detached."""
+        if isinstance(self.sync, BucketedSync):
+            self.sync.enabled = on
+        elif on:
+            self.sync = self._sync_saved
+        else:
+            self._sync_saved = self.sync
+            self.sync = NoSync(self.comm, self.cfg.resolved_grad_reduce())
+
+    def comm_only_step(self) -> None:
+        self.sync.comm_only()
+
     def train_step(self, data: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         self.flat.zero_grad()
         self.sync.prepare_forward()

@@ -147,6 +147,25 @@ class Trainer:
             test_loss, n_ok, total, 100. * n_ok / max(total, 1)))
         return {"test_loss": test_loss, "correct": n_ok, "total": total}
 
+    # ------------------------------------------------------- comm/compute split
+    def comm_split(self, loader, batches: int = 4, steps: int = 10):
+        """Communication / compute split and overlap fraction of this run's sync mode (the
+        reference derived it from separate 1-node and N-node runs, group25.pdf p10).  Runs
+        last: parameters keep training and ranks drift apart during the measurement."""
+        from ..utils.overlap import format_comm_split, measure_comm_split
+        if self.comm is None or self.world < 1 or self.cfg.sync == SYNC_NONE:
+            return None
+        held = []
+        for i, batch in enumerate(loader):
+            if i == batches:
+                break
+            held.append(batch)
+        self.backend.train_mode(True)
+        split = measure_comm_split(self.backend, self.comm, held, n=steps)
+        if split is not None:
+            print(format_comm_split(self.cfg.sync, split))
+        return split
+
     # ------------------------------------------------------------------- run
     def run(self) -> Dict[str, object]:
         cfg = self.cfg
@@ -168,6 +187,10 @@ class Trainer:
             from ..models.checkpoint import save_checkpoint
             save_checkpoint(cfg.checkpoint_out, self.backend.state_dict(),
                             ddp_prefix=cfg.sync == "ddp")
+        if cfg.report_overlap:
+            split = self.comm_split(train_loader)
+            if split is not None:
+                result["comm_split"] = split
         if cfg.json and self.rank == 0:
             rec = {"sync": cfg.sync, "world_size": self.world, "batch_size": cfg.batch_size,
                    "backend": self.backend.name, "dtype": cfg.dtype,

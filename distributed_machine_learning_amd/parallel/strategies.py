@@ -38,6 +38,9 @@ class GradSync:
         self.comm = comm
         self.reduce = reduce
 
+    def comm_only(self) -> None:            # the step's collectives and nothing else
+        self.finish()
+
     def prepare_forward(self) -> None:      # before every forward pass
         pass
 
@@ -142,6 +145,7 @@ class BucketedSync(GradSync):
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
+        self.enabled = True                 # False: hooks and broadcasts do nothing (timing aid)
         # construction-time broadcast of rank 0's state (DDP constructor behaviour)
         if comm.world_size > 1:
             comm.broadcast(flat.params, 0)
@@ -159,6 +163,8 @@ class BucketedSync(GradSync):
 
     def _make_hook(self, index: int):
         def hook(_param):
+            if not self.enabled:
+                return
             b = self._bucket_of[index]
             self._pending[b] -= 1
             if self._pending[b] == 0:
@@ -166,7 +172,7 @@ class BucketedSync(GradSync):
         return hook
 
     def prepare_forward(self) -> None:
-        if self.flat.module.training:
+        if self.enabled and self.flat.module.training:
             self._broadcast_buffers()
 
     def begin_backward(self) -> None:
@@ -174,11 +180,19 @@ class BucketedSync(GradSync):
         self._handles = []
 
     def finish(self) -> None:
+        if not self.enabled:
+            return
         if any(self._pending):
             raise RuntimeError("backward finished with gradients missing from a bucket")
         for h in self._handles:
             h.wait()
         self._handles = []
+
+    def comm_only(self) -> None:
+        self._broadcast_buffers()
+        handles = [self.comm.all_reduce_async(sl, self.reduce) for sl in self._slices]
+        for h in handles:
+            h.wait()
 
     def close(self) -> None:
         for h in self._hooks:

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--backend", default="torch")
     ap.add_argument("--dtype", default="fp32")
     ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--report-overlap", action="store_true")
     ap.add_argument("--out", required=True)
     ns = ap.parse_args()
     cfg = TrainConfig(master_ip=ns.master_ip, rank=ns.rank, num_nodes=ns.num_nodes, sync=ns.sync,
@@ -46,6 +47,11 @@ def main():
     tr.train_epoch(train_loader, 0)
     sd = {k: v.float().cpu() for k, v in tr.backend.state_dict().items()}
     torch.save(sd, f"{ns.out}.rank{ns.rank}")
+    if ns.report_overlap:
+        import json
+        split = tr.comm_split(train_loader, batches=2, steps=2)
+        with open(f"{ns.out}.split{ns.rank}", "w") as f:
+            json.dump(split, f)
     tr.close()
     if comm is not None:
         comm.destroy()
