@@ -63,6 +63,9 @@ def parse():
                          "final wgrad ({conv4, conv3} then hide behind conv2/conv1 backward and "
                          "only {conv2, conv1}, 0.3 MB, is exposed)")
     ap.add_argument("--serialize-streams", action="store_true")
+    ap.add_argument("--wgrad-overlap", type=int, default=1, choices=(0, 1),
+                    help="weight-gradient kernels on a second HIP stream")
+    ap.add_argument("--wgrad-group", type=int, default=2)
     ap.add_argument("--distinct-batches", type=int, default=4)
     ap.add_argument("--report-overlap", action="store_true",
                     help="with communication on: also time the step without collectives and the "
@@ -107,6 +110,7 @@ def main():
                                            is not None else ns.bucket_cap_mb),
                       tail_bucket_cap_mb=ns.tail_bucket_cap_mb,
                       serialize_streams=ns.serialize_streams,
+                      wgrad_overlap=bool(ns.wgrad_overlap), wgrad_group=ns.wgrad_group,
                       summary=False, eval=False)
     torch.manual_seed(SEED)
     backend = make_backend(cfg, device, comm)

@@ -56,6 +56,12 @@ def build_parser(defaults: TrainConfig, distributed_flags: bool = True) -> argpa
     p.add_argument("--no-summary", dest="summary", action="store_false", default=defaults.summary)
     p.add_argument("--json", action="store_true", default=defaults.json)
     p.add_argument("--graph", dest="use_graph", action="store_true", default=defaults.use_graph)
+    wo = p.add_mutually_exclusive_group()
+    wo.add_argument("--wgrad-overlap", dest="wgrad_overlap", action="store_true",
+                    default=defaults.wgrad_overlap,
+                    help="run backward's weight-gradient kernels on a second HIP stream")
+    wo.add_argument("--no-wgrad-overlap", dest="wgrad_overlap", action="store_false")
+    p.add_argument("--wgrad-group", type=int, default=defaults.wgrad_group)
     p.add_argument("--serialize-streams", action="store_true",
                    default=defaults.serialize_streams,
                    help="debug: issue collectives on the compute stream (no overlap)")

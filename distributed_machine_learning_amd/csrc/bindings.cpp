@@ -159,6 +159,9 @@ PYBIND11_MODULE(_C, m) {
                          ptr<const float>(srstd), ptr<float>(dgamma), ptr<float>(dbeta),
                          ptr<float>(ws), batch, hw, c, st(s));
     });
+    m.def("streams_run_concurrently", [](uintptr_t busy, uintptr_t candidate) {
+        return streams_run_concurrently((hipStream_t)busy, (hipStream_t)candidate);
+    });
     m.def("fc_train", [](uintptr_t x, uintptr_t w, uintptr_t b, uintptr_t target, uintptr_t logits,
                          uintptr_t loss, uintptr_t correct, uintptr_t dx, uintptr_t dw, uintptr_t db,
                          uintptr_t ws, int batch, int in_f, int out_f, uintptr_t s) {

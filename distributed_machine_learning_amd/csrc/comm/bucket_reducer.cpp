@@ -13,6 +13,7 @@
 #include <stdexcept>
 
 #include "dml_comm.h"
+#include "dml_kernels.h"
 
 namespace py = pybind11;
 
@@ -49,14 +50,15 @@ void check_hip(hipError_t e, const char* what) {
 }  // namespace
 
 BucketReducer::BucketReducer(RcclComm* comm, float* flat_grads, std::vector<Slice> slices,
-                             bool average, bool serialize)
+                             bool average, bool serialize, hipStream_t compute_stream)
     : comm_(comm), grads_(flat_grads), slices_(std::move(slices)), average_(average),
       serialize_(serialize) {
     if (!comm_) throw std::invalid_argument("BucketReducer: communicator missing");
     // Default priority on purpose: with a high-priority communication stream the
     // event hand-off with the compute stream was observed to stall on MI355X / ROCm 7.
-    if (!serialize_)
-        check_hip(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking), "hipStreamCreate");
+    // The stream is probed to sit on a hardware queue of its own: on a queue shared with the
+    // compute stream the collectives would simply run in line with backward.
+    if (!serialize_) comm_stream_ = create_concurrent_stream({compute_stream});
     ready_.resize(slices_.size());
     done_.resize(slices_.size());
     launched_.assign(slices_.size(), 0);
@@ -222,11 +224,13 @@ void bind_comm(py::module_& m) {
     py::class_<BucketReducer>(m, "BucketReducer")
         .def(py::init([](RcclComm* comm, uintptr_t grads,
                          std::vector<std::pair<size_t, size_t>> slices, bool average,
-                         bool serialize) {
+                         bool serialize, uintptr_t compute_stream) {
             std::vector<BucketReducer::Slice> s;
             for (auto& p : slices) s.push_back({p.first, p.second});
-            return new BucketReducer(comm, (float*)grads, s, average, serialize);
-        }), py::keep_alive<1, 2>())
+            return new BucketReducer(comm, (float*)grads, s, average, serialize,
+                                     (hipStream_t)compute_stream);
+        }), py::arg("comm"), py::arg("grads"), py::arg("slices"), py::arg("average"),
+            py::arg("serialize"), py::arg("compute_stream") = 0, py::keep_alive<1, 2>())
         .def_property_readonly("num_buckets", &BucketReducer::num_buckets)
         .def("begin_step", &BucketReducer::begin_step)
         .def("bucket_ready", [](BucketReducer& r, int b, uintptr_t s) {

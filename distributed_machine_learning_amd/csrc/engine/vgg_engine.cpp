@@ -120,8 +120,14 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         c.pool_off = a;
         if (c.pool_after) a = align_up(a + act / 4);
     }
-    gbuf_off_[0] = a; a = align_up(a + max_act);
-    gbuf_off_[1] = a; a = align_up(a + max_act);
+    // Gradients: one buffer per layer for dL/d(conv output) (read by that layer's dgrad and,
+    // possibly much later on the side stream, by its wgrad), plus one transit buffer for the
+    // gradient arriving at a layer that still has pool / BatchNorm / ReLU backward to apply.
+    for (Conv& c : convs_) {
+        c.gout_off = a;
+        a = align_up(a + B * c.hw * c.hw * c.cout);
+    }
+    gin_off_ = a; a = align_up(a + max_act);
     arena_elems_ = a;
 
     // ---- fp32 workspace
@@ -178,6 +184,72 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
 VggEngine::~VggEngine() {
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
     if (graph_) (void)hipGraphDestroy(graph_);
+    for (hipEvent_t e : hand_off_) (void)hipEventDestroy(e);
+    if (side_done_) (void)hipEventDestroy(side_done_);
+    if (wgrad_stream_) (void)hipStreamDestroy(wgrad_stream_);
+}
+
+void VggEngine::set_wgrad_overlap(bool on, int group, hipStream_t compute_stream) {
+    if (group < 1) throw std::invalid_argument("VggEngine: wgrad group must be >= 1");
+    if (on && !wgrad_stream_) {
+        // on a hardware queue shared with the compute (or communication) stream the weight
+        // gradients would run in line with it: probe for a queue of its own
+        std::vector<hipStream_t> avoid = {compute_stream};
+        if (reducer_ && reducer_->comm_stream()) avoid.push_back(reducer_->comm_stream());
+        wgrad_stream_ = create_concurrent_stream(avoid);
+        hand_off_.resize(convs_.size());
+        for (hipEvent_t& e : hand_off_)
+            check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&side_done_, hipEventDisableTiming), "hipEventCreate");
+    }
+    if ((on != wgrad_overlap_ || group != wgrad_group_) && graph_exec_) {
+        (void)hipGraphExecDestroy(graph_exec_);     // a captured step has the old schedule
+        graph_exec_ = nullptr;
+    }
+    wgrad_overlap_ = on;
+    wgrad_group_ = group;
+}
+
+void VggEngine::join_wgrad_stream(hipStream_t stream) {
+    if (!side_busy_) return;
+    check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
+    check_hip(hipStreamWaitEvent(stream, side_done_, 0), "hipStreamWaitEvent(side done)");
+    side_busy_ = false;
+}
+
+// Weight (and, without BatchNorm, bias) gradient of one conv layer after the first.
+void VggEngine::launch_wgrad(int i, int batch, hipStream_t stream) {
+    const Conv& c = convs_[i];
+    const Conv& prev = convs_[i - 1];
+    const uint16_t* in = arena_ + (prev.pool_after ? prev.pool_off : prev.out_off);
+    const uint16_t* g = arena_ + c.gout_off;
+    const ConvShape s = {batch, c.hw, c.cin, c.cout};
+    // Conv bias gradient.  Under BatchNorm it is exactly zero in exact arithmetic (the
+    // normalisation removes any per-channel offset; a framework's value there is rounding
+    // noise), so it is left at the zero the buffer was allocated with.  Without BatchNorm
+    // nothing else in a backward pass touches the reduction scratch.
+    if (!bn_) column_sum(g, grads_ + c.b_off, batch * c.hw * c.hw, c.cout, ws_ + stats_off_, stream);
+    conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream, 0, ws_ + c.wslab_off);
+    const int splits = conv3x3_wgrad_splits(s);
+    if (splits > 1) {       // partial results per split, summed by flush_wgrad_sums
+        if (wgrad_sums_.n == SlabSumJobs::kMax) flush_wgrad_sums(stream);
+        const int j = wgrad_sums_.n++;
+        wgrad_sums_.src_off[j] = c.wslab_off;
+        wgrad_sums_.dst_off[j] = c.w_off;
+        wgrad_sums_.count[j] = (size_t)c.cout * 9 * c.cin;
+        wgrad_sums_.splits[j] = splits;
+    }
+}
+
+// Side-stream mode: everything the main stream had produced when hand_off_[layer] was recorded
+// (the queued layers' gradients, the BatchNorm / classifier gradients of a departing bucket)
+// becomes visible to the side stream, which then runs the queued weight gradients and their sums.
+void VggEngine::hand_off_wgrads(int layer, int batch) {
+    check_hip(hipStreamWaitEvent(wgrad_stream_, hand_off_[layer], 0), "hipStreamWaitEvent(hand-off)");
+    for (int i : wgrad_queue_) launch_wgrad(i, batch, wgrad_stream_);
+    wgrad_queue_.clear();
+    flush_wgrad_sums(wgrad_stream_);
+    side_busy_ = true;
 }
 
 void VggEngine::bind(float* params, float* grads, float* momentum, float* bn_buffers,
@@ -323,69 +395,85 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     float* slab = ws_ + slab_off_;
     const Conv& last = convs_[nconv - 1];
     const uint16_t* fc_in = arena_ + (last.pool_after ? last.pool_off : last.out_off);
-    int cur = 0;        // index of the ping-pong buffer holding the incoming gradient
+    const bool side = wgrad_overlap_;
+    uint16_t* transit = arena_ + gin_off_;
+    // where the gradient arriving at layer i is written: its own buffer when it already is
+    // dL/d(conv output) (no BatchNorm, no pool: the producer applied the ReLU mask), else transit
+    auto staged = [&](int i) { return bn_ || convs_[i].pool_after; };
+    auto arriving = [&](int i) { return staged(i) ? transit : arena_ + convs_[i].gout_off; };
+    auto bucket_leaves = [&](int layer) { return reducer_ && !buckets_by_layer_[layer].empty(); };
+
     // classifier + loss, forward and backward, in two launches; every output is overwritten
     fc_train(fc_in, params_ + fcw_off_, params_ + fcb_off_, target, ws_ + logits_off_,
-             ws_ + loss_off_, nullptr, arena_ + gbuf_off_[cur], grads_ + fcw_off_, grads_ + fcb_off_,
+             ws_ + loss_off_, nullptr, arriving(nconv - 1), grads_ + fcw_off_, grads_ + fcb_off_,
              ws_ + fc_ws_off_, batch, fc_in_, num_classes_, stream);
-    fire_buckets(nconv, stream);
+    // side mode: a completed bucket leaves (from the side stream) with the next hand-off
+    std::vector<int> owed;          // layers whose buckets are complete but not yet sent off
+    if (!side) fire_buckets(nconv, stream);
+    else if (bucket_leaves(nconv)) owed.push_back(nconv);
     for (int i = nconv - 1; i >= 0; --i) {
         const Conv& c = convs_[i];
         const int rows = batch * c.hw * c.hw;
-        if (bn_ && c.pool_after) {
-            bn_relu_pool_bwd(arena_ + c.pre_off, arena_ + gbuf_off_[cur], arena_ + gbuf_off_[cur ^ 1],
-                             params_ + c.gamma_off, params_ + c.beta_off, ws_ + c.save_off,
-                             ws_ + c.save_off + c.cout, grads_ + c.gamma_off, grads_ + c.beta_off,
-                             ws_ + stats_off_, batch, c.hw, c.cout, stream);
-            cur ^= 1;
-        } else {
-            if (c.pool_after) {
-                maxpool2x2_bwd(arena_ + c.out_off, arena_ + gbuf_off_[cur],
-                               arena_ + gbuf_off_[cur ^ 1], batch, c.hw, c.cout,
-                               /*relu_mask=*/!bn_, stream);
-                cur ^= 1;
-            }
-            if (bn_) {
-                bn_relu_bwd(arena_ + c.pre_off, arena_ + gbuf_off_[cur], arena_ + gbuf_off_[cur ^ 1],
-                            params_ + c.gamma_off, params_ + c.beta_off, ws_ + c.save_off,
-                            ws_ + c.save_off + c.cout, grads_ + c.gamma_off, grads_ + c.beta_off,
-                            ws_ + stats_off_, rows, c.cout, stream);
-                cur ^= 1;
-            }
-        }
-        const uint16_t* g = arena_ + gbuf_off_[cur];       // dL/d(conv output), mask applied
+        uint16_t* g = arena_ + c.gout_off;       // dL/d(conv output), ReLU mask applied
+        if (bn_ && c.pool_after)
+            bn_relu_pool_bwd(arena_ + c.pre_off, transit, g, params_ + c.gamma_off,
+                             params_ + c.beta_off, ws_ + c.save_off, ws_ + c.save_off + c.cout,
+                             grads_ + c.gamma_off, grads_ + c.beta_off, ws_ + stats_off_, batch,
+                             c.hw, c.cout, stream);
+        else if (c.pool_after)
+            maxpool2x2_bwd(arena_ + c.out_off, transit, g, batch, c.hw, c.cout, /*relu_mask=*/true,
+                           stream);
+        else if (bn_)
+            bn_relu_bwd(arena_ + c.pre_off, transit, g, params_ + c.gamma_off, params_ + c.beta_off,
+                        ws_ + c.save_off, ws_ + c.save_off + c.cout, grads_ + c.gamma_off,
+                        grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream);
         if (i == 0) {
+            // shares the split-K slab with the input-gradient kernels: always on the main stream
             conv1_wgrad(x, g, grads_ + c.w_off, bn_ ? nullptr : grads_ + c.b_off, batch, slab,
                         stream);
+        } else if (side) {
+            wgrad_queue_.push_back(i);
         } else {
-            const Conv& prev = convs_[i - 1];
-            const uint16_t* in = arena_ + (prev.pool_after ? prev.pool_off : prev.out_off);
-            ConvShape s = {batch, c.hw, c.cin, c.cout};
-            // Conv bias gradient.  Under BatchNorm it is exactly zero in exact arithmetic (the
-            // normalisation removes any per-channel offset; a framework's value there is
-            // rounding noise), so it is left at the zero the buffer was allocated with.
-            if (!bn_) column_sum(g, grads_ + c.b_off, rows, c.cout, ws_ + stats_off_, stream);
-            conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream, 0, ws_ + c.wslab_off);
-            const int splits = conv3x3_wgrad_splits(s);
-            if (splits > 1) {
-                if (wgrad_sums_.n == SlabSumJobs::kMax) flush_wgrad_sums(stream);
-                const int j = wgrad_sums_.n++;
-                wgrad_sums_.src_off[j] = c.wslab_off;
-                wgrad_sums_.dst_off[j] = c.w_off;
-                wgrad_sums_.count[j] = (size_t)c.cout * 9 * c.cin;
-                wgrad_sums_.splits[j] = splits;
-            }
+            launch_wgrad(i, batch, stream);
+        }
+        // Side mode: one hand-off serves a whole group of layers and every bucket completed
+        // since the last one.  The event is recorded before this layer's dgrad (the side stream
+        // need not wait for it), but the side stream's launches are issued after it so that
+        // the main chain - the critical path - is enqueued first.
+        bool hand = false;
+        if (side) {
+            if (bucket_leaves(i)) owed.push_back(i);
+            const bool full = (int)wgrad_queue_.size() >= wgrad_group_ ||
+                              (i <= 1 && !wgrad_queue_.empty());
+            hand = full || bucket_leaves(i) || (i == 0 && !owed.empty());
+            if (hand) check_hip(hipEventRecord(hand_off_[i], stream), "hipEventRecord(hand-off)");
+        }
+        if (i > 0) {
             // input gradient; the producer's ReLU is folded in when nothing sits in between
+            const Conv& prev = convs_[i - 1];
             ConvShape d = {batch, c.hw, c.cout, c.cin};
-            const bool fold_relu = !prev.pool_after && !bn_;
-            conv3x3_igemm(g, arena_ + c.wd_off, arena_ + gbuf_off_[cur ^ 1], nullptr,
+            const bool fold_relu = !staged(i - 1);
+            conv3x3_igemm(g, arena_ + c.wd_off, arriving(i - 1), nullptr,
                           fold_relu ? arena_ + prev.out_off : nullptr, slab, slab_elems_, d,
                           fold_relu ? EPI_MASK : EPI_NONE, stream);
-            cur ^= 1;
         }
-        fire_buckets(i, stream);
+        if (hand) {
+            hand_off_wgrads(i, batch);
+            for (int l : owed)
+                for (int b : buckets_by_layer_[l]) reducer_->bucket_ready(b, wgrad_stream_);
+            owed.clear();
+        }
+        if (!side) fire_buckets(i, stream);
     }
-    flush_wgrad_sums(stream);
+    if (side) {
+        // with a reducer the last bucket left from the side stream after all of its work, and
+        // the optimizer waits for that bucket; otherwise the main stream waits here (this also
+        // rejoins the side stream into a graph capture)
+        if (reducer_ && bucket_leaves(0)) side_busy_ = false;
+        join_wgrad_stream(stream);
+    } else {
+        flush_wgrad_sums(stream);
+    }
 }
 
 void VggEngine::forward_backward(const uint16_t* x, const int64_t* target, int batch,
@@ -470,6 +558,11 @@ void bind_engine(py::module_& m) {
                         uintptr_t arena, uintptr_t ws) {
             e.bind((float*)p, (float*)g, (float*)mo, (float*)bn, (uint16_t*)arena, (float*)ws);
         })
+        .def("set_wgrad_overlap", [](VggEngine& e, bool on, int group, uintptr_t compute_stream) {
+            e.set_wgrad_overlap(on, group, (hipStream_t)compute_stream);
+        }, py::arg("on"), py::arg("group") = 2, py::arg("compute_stream") = 0)
+        .def_property_readonly("wgrad_overlap", &VggEngine::wgrad_overlap)
+        .def_property_readonly("wgrad_stream", [](VggEngine& e) { return (uintptr_t)e.wgrad_stream(); })
         .def("set_reducer", [](VggEngine& e, BucketReducer* r,
                                std::vector<std::pair<int, int>> buckets) {
             std::vector<BucketRange> b;

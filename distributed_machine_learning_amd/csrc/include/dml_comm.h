@@ -118,8 +118,10 @@ std::vector<BucketRange> plan_buckets(const std::vector<size_t>& sizes_bytes, si
 class BucketReducer {
   public:
     struct Slice { size_t offset, count; };
+    // compute_stream: the stream backward runs on (the communication stream is chosen to
+    // execute concurrently with it)
     BucketReducer(RcclComm* comm, float* flat_grads, std::vector<Slice> slices, bool average,
-                  bool serialize);
+                  bool serialize, hipStream_t compute_stream = nullptr);
     ~BucketReducer();
     int num_buckets() const { return (int)slices_.size(); }
     void begin_step();

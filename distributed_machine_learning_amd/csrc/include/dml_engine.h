@@ -55,6 +55,14 @@ class VggEngine {
     void bind(float* params, float* grads, float* momentum, float* bn_buffers, uint16_t* arena,
               float* workspace);
     void set_reducer(BucketReducer* reducer, const std::vector<BucketRange>& buckets);
+    // Run the weight-gradient kernels of backward (with their partial-result sums, and the
+    // gradient buckets' departure) on a second HIP stream, next to the input-gradient /
+    // BatchNorm chain they do not depend on.  Results are identical: every kernel is
+    // deterministic and the hand-offs are event-ordered.  Work is handed over in groups of
+    // `group` layers because a cross-stream dependency costs ~15 us of host time on ROCm.
+    void set_wgrad_overlap(bool on, int group = 2, hipStream_t compute_stream = nullptr);
+    bool wgrad_overlap() const { return wgrad_overlap_; }
+    hipStream_t wgrad_stream() const { return wgrad_stream_; }
 
     // bf16 shadow + conv1 / dgrad repacks from the fp32 master weights
     void refresh_weights(hipStream_t stream);
@@ -101,10 +109,14 @@ class VggEngine {
         size_t wd_off;                                // arena: dgrad-layout weights
         size_t wslab_off;                             // workspace: wgrad partial results per split
         size_t pre_off, out_off, pool_off;            // arena: activations
+        size_t gout_off;                              // arena: dL/d(conv output), read by dgrad + wgrad
     };
     void backward(const uint16_t* x_nhwc4, const int64_t* target, int batch, hipStream_t stream);
     void fire_buckets(int layer, hipStream_t stream);
     void flush_wgrad_sums(hipStream_t stream);
+    void join_wgrad_stream(hipStream_t stream);
+    void hand_off_wgrads(int layer, int batch);
+    void launch_wgrad(int layer, int batch, hipStream_t stream);
     void repack_all(hipStream_t stream);
 
     std::vector<Conv> convs_;
@@ -112,7 +124,7 @@ class VggEngine {
     bool bn_;
     size_t fcw_off_ = 0, fcb_off_ = 0;
     size_t param_elems_ = 0, bn_elems_ = 0, arena_elems_ = 0, ws_elems_ = 0;
-    size_t shadow_off_ = 0, w1_off_ = 0, gbuf_off_[2] = {0, 0};
+    size_t shadow_off_ = 0, w1_off_ = 0, gin_off_ = 0;
     size_t logits_off_ = 0, dlogits_off_ = 0, loss_off_ = 0, stats_off_ = 0, slab_off_ = 0,
            cstats_off_ = 0, fc_ws_off_ = 0;
     SlabSumJobs wgrad_sums_;      // partial-result reductions not yet launched
@@ -123,6 +135,13 @@ class VggEngine {
     BucketReducer* reducer_ = nullptr;
     std::vector<std::vector<int>> buckets_by_layer_;   // layer -> bucket ids to fire
     long long bn_steps_ = 0;
+    bool wgrad_overlap_ = false;
+    hipStream_t wgrad_stream_ = nullptr;
+    int wgrad_group_ = 2;
+    std::vector<hipEvent_t> hand_off_;      // per layer: main-stream position the side stream waits for
+    hipEvent_t side_done_ = nullptr;
+    std::vector<int> wgrad_queue_;          // layers whose gradient is ready, wgrad not yet launched
+    bool side_busy_ = false;                // side-stream work the main stream has not waited for
     hipGraph_t graph_ = nullptr;
     hipGraphExec_t graph_exec_ = nullptr;
 };

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace dml {
 
 typedef uint16_t bf16_raw;   // bf16 bit pattern in host-visible signatures
@@ -198,5 +200,12 @@ void nhwc_bf16_to_nchw_f32(const bf16_raw* x, float* out, int batch, int c, int 
 void sum_slabs(float* slabs, int world, size_t n, hipStream_t stream);
 // fill a bf16 buffer with uniform values in [-1, 1) from a counter hash (tests / benches)
 void fill_uniform_bf16(bf16_raw* out, size_t n, uint32_t seed, float scale, hipStream_t stream);
+
+// ---- streams on hardware queues of their own (stream_probe.hip)
+// true if a kernel on `candidate` starts while a kernel on `busy` is still running
+bool streams_run_concurrently(hipStream_t busy, hipStream_t candidate);
+// a non-blocking stream that runs concurrently with every stream in `avoid` (falls back to
+// the last candidate, with a warning, when the hardware-queue pool is exhausted)
+hipStream_t create_concurrent_stream(const std::vector<hipStream_t>& avoid, int max_tries = 8);
 
 }  // namespace dml

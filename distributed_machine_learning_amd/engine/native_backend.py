@@ -63,6 +63,10 @@ class NativeBackend:
         self.reducer = None
         self._grad_scale = 1.0
         self.sync = self._build_sync()
+        # after the reducer exists: the side stream must share a hardware queue with neither
+        # the compute stream nor the communication stream
+        e.set_wgrad_overlap(bool(cfg.wgrad_overlap) and not cfg.serialize_streams,
+                            int(cfg.wgrad_group), self._stream())
         self._graph_ready = False
         self._x_static = None
         self._t_static = None
@@ -108,7 +112,7 @@ class NativeBackend:
             # buckets are summed (RCCL's plain-sum path); the 1/world of "mean" is folded into
             # the fused SGD kernel's gradient scale, where it is free
             self.reducer = C.BucketReducer(comm.native, self.grads.data_ptr(), slices, False,
-                                           cfg.serialize_streams)
+                                           cfg.serialize_streams, self._stream())
             self._grad_scale = 1.0 / self.world if reduce == "mean" else 1.0
             self.engine.set_reducer(self.reducer, buckets)
             if stage:

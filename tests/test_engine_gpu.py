@@ -326,6 +326,62 @@ def test_training_is_bit_reproducible(batch_norm):
         assert torch.equal(a.bn_buffers, b.bn_buffers)
 
 
+@pytest.mark.parametrize("batch_norm", [False, True])
+@pytest.mark.parametrize("mode", ["eager", "graph", "ddp"])
+def test_wgrad_side_stream_matches_single_stream(batch_norm, mode):
+    """Race check for the second compute stream: weight-gradient kernels running next to the
+    input-gradient chain (rotating gradient buffers, event hand-offs, joins before the slab sums
+    and before a bucket leaves) must reproduce the single-stream schedule bit for bit."""
+    comm = None
+    kw = {}
+    if mode == "graph":
+        kw["use_graph"] = True
+    if mode == "ddp":
+        from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
+        comm = RcclCommunicator(f"127.0.0.1:{29620 + int(batch_norm)}", 0, 1, 0, timeout_s=60)
+        kw.update(sync="ddp", comm=comm, bucket_cap_mb=1.0)
+    try:
+        base, _ = _mk(batch_norm, batch=64, wgrad_overlap=False)
+        side, _ = _mk(batch_norm, batch=64, wgrad_overlap=True, **kw)
+        assert side.engine.wgrad_overlap and not base.engine.wgrad_overlap
+        for step in range(5):
+            _, x4, t = _batch(64, seed=step)
+            la = base.train_step(x4, t).clone()
+            lb = side.train_step(x4, t).clone()
+            assert torch.equal(la, lb), (step, float(la), float(lb))
+        torch.cuda.synchronize()
+        assert torch.equal(side.params, base.params)
+        assert torch.equal(side.momentum, base.momentum)
+        if batch_norm:
+            assert torch.equal(side.bn_buffers, base.bn_buffers)
+        side.close()
+    finally:
+        if comm is not None:
+            comm.destroy()
+
+
+def test_side_streams_sit_on_their_own_hardware_queues():
+    """HIP shares a few hardware queues among all streams, and streams on one queue run in
+    line: the communication stream and the weight-gradient stream are probed at creation, so
+    both must really execute next to the compute stream and next to each other."""
+    from distributed_machine_learning_amd.ops import native
+    from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
+    C = native.lib()
+    main = int(torch.cuda.current_stream().cuda_stream)
+    assert not C.streams_run_concurrently(main, main)
+    comm = RcclCommunicator("127.0.0.1:29631", 0, 1, 0, timeout_s=60)
+    try:
+        nb, _ = _mk(True, sync="ddp", comm=comm, wgrad_overlap=True)
+        cs, ws = nb.reducer.comm_stream, nb.engine.wgrad_stream
+        assert cs and ws and cs != ws
+        assert C.streams_run_concurrently(main, cs)
+        assert C.streams_run_concurrently(main, ws)
+        assert C.streams_run_concurrently(cs, ws)
+        nb.close()
+    finally:
+        comm.destroy()
+
+
 def test_graph_replay_matches_eager():
     eager, _ = _mk(False)
     graph, _ = _mk(False, use_graph=True)
