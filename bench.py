@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--wgrad-overlap", type=int, default=1, choices=(0, 1),
                     help="weight-gradient kernels on a second HIP stream")
     ap.add_argument("--wgrad-group", type=int, default=2)
+    ap.add_argument("--fused-optimizer", type=int, default=0, choices=(0, 1),
+                    help="SGD slices inside backward, behind each group's / bucket's gradients")
     ap.add_argument("--distinct-batches", type=int, default=4)
     ap.add_argument("--report-overlap", action="store_true",
                     help="with communication on: also time the step without collectives and the "
@@ -111,6 +113,7 @@ def main():
                       tail_bucket_cap_mb=ns.tail_bucket_cap_mb,
                       serialize_streams=ns.serialize_streams,
                       wgrad_overlap=bool(ns.wgrad_overlap), wgrad_group=ns.wgrad_group,
+                      fused_optimizer=bool(ns.fused_optimizer),
                       summary=False, eval=False)
     torch.manual_seed(SEED)
     backend = make_backend(cfg, device, comm)

@@ -62,6 +62,10 @@ def build_parser(defaults: TrainConfig, distributed_flags: bool = True) -> argpa
                     help="run backward's weight-gradient kernels on a second HIP stream")
     wo.add_argument("--no-wgrad-overlap", dest="wgrad_overlap", action="store_false")
     p.add_argument("--wgrad-group", type=int, default=defaults.wgrad_group)
+    p.add_argument("--fused-optimizer", dest="fused_optimizer", action="store_true",
+                   default=defaults.fused_optimizer,
+                   help="optimizer update in slices inside backward (behind each group's sums / "
+                        "each bucket's all-reduce) instead of one launch after it")
     p.add_argument("--serialize-streams", action="store_true",
                    default=defaults.serialize_streams,
                    help="debug: issue collectives on the compute stream (no overlap)")

@@ -63,6 +63,7 @@ class TrainConfig:
     threads: int = 4                       # torch.set_num_threads(4), part1/main.py:16
     use_graph: bool = False                # capture the native train step in a hipGraph
     wgrad_overlap: bool = True             # weight-gradient kernels on a second HIP stream
+    fused_optimizer: bool = False          # SGD slices inside backward (needs wgrad_overlap)
     wgrad_group: int = 2                   # layers handed to that stream per cross-stream event
 
     # --- data ---

@@ -79,7 +79,8 @@ void BucketReducer::begin_step() {
     last_ready_ = -1;
 }
 
-void BucketReducer::bucket_ready(int b, hipStream_t compute) {
+void BucketReducer::bucket_ready(int b, hipStream_t compute,
+                                 const std::function<void(hipStream_t)>& after) {
     if (b < 0 || b >= (int)slices_.size()) throw std::out_of_range("BucketReducer: bucket index");
     if (launched_[b]) throw std::logic_error("BucketReducer: bucket marked ready twice");
     launched_[b] = 1;
@@ -87,11 +88,13 @@ void BucketReducer::bucket_ready(int b, hipStream_t compute) {
     const Slice& s = slices_[b];
     if (serialize_) {       // debug mode: same stream, no overlap, no events
         comm_->all_reduce(grads_ + s.offset, s.count, DT_F32, average_, compute);
+        if (after) after(compute);
         return;
     }
     check_hip(hipEventRecord(ready_[b], compute), "hipEventRecord(ready)");
     check_hip(hipStreamWaitEvent(comm_stream_, ready_[b], 0), "hipStreamWaitEvent(comm)");
     comm_->all_reduce(grads_ + s.offset, s.count, DT_F32, average_, comm_stream_);
+    if (after) after(comm_stream_);
     check_hip(hipEventRecord(done_[b], comm_stream_), "hipEventRecord(done)");
 }
 

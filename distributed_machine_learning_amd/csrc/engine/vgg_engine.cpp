@@ -13,6 +13,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <functional>
 #include <stdexcept>
 
 #include "dml_kernels.h"
@@ -210,6 +211,23 @@ void VggEngine::set_wgrad_overlap(bool on, int group, hipStream_t compute_stream
     wgrad_group_ = group;
 }
 
+void VggEngine::set_fused_optimizer(bool on, float lr, float momentum, float weight_decay,
+                                    float grad_scale) {
+    opt_.on = on; opt_.lr = lr; opt_.mu = momentum; opt_.wd = weight_decay; opt_.gscale = grad_scale;
+}
+
+size_t VggEngine::layer_begin(int layer) const {
+    for (const SlotInfo& s : slots_)
+        if (s.layer >= layer) return s.offset;
+    return param_elems_;
+}
+
+void VggEngine::sgd_slice(size_t begin, size_t end, hipStream_t stream) {
+    if (end <= begin) return;
+    sgd_momentum(params_ + begin, grads_ + begin, mom_ + begin, arena_ + shadow_off_ + begin,
+                 end - begin, opt_.lr, opt_.mu, opt_.wd, opt_.gscale, false, stream);
+}
+
 void VggEngine::join_wgrad_stream(hipStream_t stream) {
     if (!side_busy_) return;
     check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
@@ -263,7 +281,9 @@ void VggEngine::bind(float* params, float* grads, float* momentum, float* bn_buf
 void VggEngine::set_reducer(BucketReducer* reducer, const std::vector<BucketRange>& buckets) {
     reducer_ = reducer;
     buckets_by_layer_.assign(convs_.size() + 1, {});
+    bucket_ranges_.clear();
     if (!reducer) return;
+    bucket_ranges_ = buckets;
     if ((int)buckets.size() != reducer->num_buckets())
         throw std::invalid_argument("VggEngine::set_reducer: bucket count mismatch");
     for (size_t b = 0; b < buckets.size(); ++b) {
@@ -396,6 +416,17 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     const Conv& last = convs_[nconv - 1];
     const uint16_t* fc_in = arena_ + (last.pool_after ? last.pool_off : last.out_off);
     const bool side = wgrad_overlap_;
+    const bool fuse_opt = side && opt_.on;
+    opt_applied_ = fuse_opt;
+    int updated_above = nconv + 1;      // layers >= this already had their parameters updated
+    // behind a bucket's all-reduce, on the stream that ran it: the update of its parameters
+    auto bucket_update = [&](int b) -> std::function<void(hipStream_t)> {
+        if (!fuse_opt) return nullptr;
+        const BucketRange r = bucket_ranges_[b];
+        const size_t begin = slots_[r.lo].offset;
+        const size_t end = r.hi < (int)slots_.size() ? slots_[r.hi].offset : param_elems_;
+        return [this, begin, end](hipStream_t s) { sgd_slice(begin, end, s); };
+    };
     uint16_t* transit = arena_ + gin_off_;
     // where the gradient arriving at layer i is written: its own buffer when it already is
     // dL/d(conv output) (no BatchNorm, no pool: the producer applied the ReLU mask), else transit
@@ -445,6 +476,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             if (bucket_leaves(i)) owed.push_back(i);
             const bool full = (int)wgrad_queue_.size() >= wgrad_group_ ||
                               (i <= 1 && !wgrad_queue_.empty());
+            // (without a reducer the last layer's few parameters finish on the main stream)
             hand = full || bucket_leaves(i) || (i == 0 && !owed.empty());
             if (hand) check_hip(hipEventRecord(hand_off_[i], stream), "hipEventRecord(hand-off)");
         }
@@ -460,8 +492,14 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
         if (hand) {
             hand_off_wgrads(i, batch);
             for (int l : owed)
-                for (int b : buckets_by_layer_[l]) reducer_->bucket_ready(b, wgrad_stream_);
+                for (int b : buckets_by_layer_[l])
+                    reducer_->bucket_ready(b, wgrad_stream_, bucket_update(b));
             owed.clear();
+            if (fuse_opt && !reducer_) {
+                // the gradients of layers i.. (and the classifier) are final behind the sums
+                sgd_slice(layer_begin(i), layer_begin(updated_above), wgrad_stream_);
+                updated_above = i;
+            }
         }
         if (!side) fire_buckets(i, stream);
     }
@@ -471,6 +509,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
         // rejoins the side stream into a graph capture)
         if (reducer_ && bucket_leaves(0)) side_busy_ = false;
         join_wgrad_stream(stream);
+        if (fuse_opt && !reducer_) sgd_slice(0, layer_begin(updated_above), stream);
     } else {
         flush_wgrad_sums(stream);
     }
@@ -493,8 +532,15 @@ void VggEngine::forward_backward(const uint16_t* x, const int64_t* target, int b
 void VggEngine::optimizer_step(float lr, float momentum, float weight_decay, float grad_scale,
                                hipStream_t stream) {
     if (reducer_) reducer_->wait_all(stream);
-    sgd_momentum(params_, grads_, mom_, arena_ + shadow_off_, param_elems_, lr, momentum,
-                 weight_decay, grad_scale, false, stream);
+    if (opt_applied_) {
+        if (lr != opt_.lr || momentum != opt_.mu || weight_decay != opt_.wd || grad_scale != opt_.gscale)
+            throw std::logic_error("VggEngine: optimizer_step() disagrees with the hyper-parameters "
+                                   "the fused update already applied in backward");
+        opt_applied_ = false;
+    } else {
+        sgd_momentum(params_, grads_, mom_, arena_ + shadow_off_, param_elems_, lr, momentum,
+                     weight_decay, grad_scale, false, stream);
+    }
     repack_conv1_weights(params_ + convs_[0].w_off, arena_ + w1_off_, stream);
     repack_all(stream);
 }
@@ -561,6 +607,9 @@ void bind_engine(py::module_& m) {
         .def("set_wgrad_overlap", [](VggEngine& e, bool on, int group, uintptr_t compute_stream) {
             e.set_wgrad_overlap(on, group, (hipStream_t)compute_stream);
         }, py::arg("on"), py::arg("group") = 2, py::arg("compute_stream") = 0)
+        .def("set_fused_optimizer", &VggEngine::set_fused_optimizer, py::arg("on"),
+             py::arg("lr") = 0.f, py::arg("momentum") = 0.f, py::arg("weight_decay") = 0.f,
+             py::arg("grad_scale") = 1.f)
         .def_property_readonly("wgrad_overlap", &VggEngine::wgrad_overlap)
         .def_property_readonly("wgrad_stream", [](VggEngine& e) { return (uintptr_t)e.wgrad_stream(); })
         .def("set_reducer", [](VggEngine& e, BucketReducer* r,

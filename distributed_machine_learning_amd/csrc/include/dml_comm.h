@@ -13,6 +13,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -125,7 +126,10 @@ class BucketReducer {
     ~BucketReducer();
     int num_buckets() const { return (int)slices_.size(); }
     void begin_step();
-    void bucket_ready(int b, hipStream_t compute);
+    // `after` (optional) is enqueued behind the bucket's all-reduce on the stream that ran it,
+    // before the bucket counts as done - e.g. the optimizer update of the bucket's parameters
+    void bucket_ready(int b, hipStream_t compute,
+                      const std::function<void(hipStream_t)>& after = nullptr);
     void wait_all(hipStream_t compute);
     hipStream_t comm_stream() const { return comm_stream_; }
 

@@ -61,6 +61,12 @@ class VggEngine {
     // deterministic and the hand-offs are event-ordered.  Work is handed over in groups of
     // `group` layers because a cross-stream dependency costs ~15 us of host time on ROCm.
     void set_wgrad_overlap(bool on, int group = 2, hipStream_t compute_stream = nullptr);
+    // Apply the SGD update inside backward (side-stream mode only), slice by slice, as soon as
+    // a slice's gradients are final: behind a group's slab sums, or behind a bucket's
+    // all-reduce on the communication stream.  Every element sees exactly the arithmetic of
+    // the single launch in optimizer_step(), which then only waits and refreshes the repacks.
+    void set_fused_optimizer(bool on, float lr = 0.f, float momentum = 0.f,
+                             float weight_decay = 0.f, float grad_scale = 1.f);
     bool wgrad_overlap() const { return wgrad_overlap_; }
     hipStream_t wgrad_stream() const { return wgrad_stream_; }
 
@@ -117,6 +123,8 @@ class VggEngine {
     void join_wgrad_stream(hipStream_t stream);
     void hand_off_wgrads(int layer, int batch);
     void launch_wgrad(int layer, int batch, hipStream_t stream);
+    size_t layer_begin(int layer) const;    // flat offset of the layer's first parameter slot
+    void sgd_slice(size_t begin, size_t end, hipStream_t stream);
     void repack_all(hipStream_t stream);
 
     std::vector<Conv> convs_;
@@ -136,6 +144,9 @@ class VggEngine {
     std::vector<std::vector<int>> buckets_by_layer_;   // layer -> bucket ids to fire
     long long bn_steps_ = 0;
     bool wgrad_overlap_ = false;
+    struct { bool on = false; float lr = 0, mu = 0, wd = 0, gscale = 1; } opt_;
+    bool opt_applied_ = false;      // this step's update already happened inside backward
+    std::vector<BucketRange> bucket_ranges_;
     hipStream_t wgrad_stream_ = nullptr;
     int wgrad_group_ = 2;
     std::vector<hipEvent_t> hand_off_;      // per layer: main-stream position the side stream waits for

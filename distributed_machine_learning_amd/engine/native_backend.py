@@ -67,6 +67,11 @@ class NativeBackend:
         # the compute stream nor the communication stream
         e.set_wgrad_overlap(bool(cfg.wgrad_overlap) and not cfg.serialize_streams,
                             int(cfg.wgrad_group), self._stream())
+        # the optimizer update can run inside backward when the gradients backward leaves
+        # behind are final: no sync, or the bucket reducer (the two manual modes synchronise
+        # after backward has ended)
+        self._fuse_opt = bool(cfg.fused_optimizer) and e.wgrad_overlap and \
+            isinstance(self.sync, NoSync)
         self._graph_ready = False
         self._x_static = None
         self._t_static = None
@@ -175,6 +180,8 @@ class NativeBackend:
         cfg, e = self.cfg, self.engine
         n = self._check_batch(data, target)
         s = self._stream()
+        e.set_fused_optimizer(self._fuse_opt, cfg.lr, cfg.momentum, cfg.weight_decay,
+                              self._grad_scale)
         if cfg.use_graph and self.world == 1:
             return self._train_step_graph(data, target, n, s)
         e.forward_backward(data.data_ptr(), target.data_ptr(), n, s)

@@ -342,19 +342,26 @@ def test_wgrad_side_stream_matches_single_stream(batch_norm, mode):
         kw.update(sync="ddp", comm=comm, bucket_cap_mb=1.0)
     try:
         base, _ = _mk(batch_norm, batch=64, wgrad_overlap=False)
-        side, _ = _mk(batch_norm, batch=64, wgrad_overlap=True, **kw)
+        side, _ = _mk(batch_norm, batch=64, wgrad_overlap=True, fused_optimizer=False, **kw)
+        fused, _ = _mk(batch_norm, batch=64, wgrad_overlap=True, fused_optimizer=True, **kw)
         assert side.engine.wgrad_overlap and not base.engine.wgrad_overlap
+        assert fused._fuse_opt and not side._fuse_opt and not base._fuse_opt
         for step in range(5):
             _, x4, t = _batch(64, seed=step)
             la = base.train_step(x4, t).clone()
             lb = side.train_step(x4, t).clone()
-            assert torch.equal(la, lb), (step, float(la), float(lb))
+            lc = fused.train_step(x4, t).clone()
+            assert torch.equal(la, lb) and torch.equal(la, lc), (step, float(la), float(lb), float(lc))
         torch.cuda.synchronize()
-        assert torch.equal(side.params, base.params)
-        assert torch.equal(side.momentum, base.momentum)
-        if batch_norm:
-            assert torch.equal(side.bn_buffers, base.bn_buffers)
+        for other in (side, fused):
+            assert torch.equal(other.params, base.params)
+            assert torch.equal(other.momentum, base.momentum)
+            assert torch.equal(other.arena[:base.engine.param_elems],
+                               base.arena[:base.engine.param_elems])      # bf16 weight shadows
+            if batch_norm:
+                assert torch.equal(other.bn_buffers, base.bn_buffers)
         side.close()
+        fused.close()
     finally:
         if comm is not None:
             comm.destroy()
