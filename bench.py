@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--serialize-streams", action="store_true")
     ap.add_argument("--wgrad-overlap", type=int, default=1, choices=(0, 1),
                     help="weight-gradient kernels on a second HIP stream")
-    ap.add_argument("--wgrad-group", type=int, default=2)
+    ap.add_argument("--wgrad-group", type=int, default=0, help="0 = auto")
     ap.add_argument("--fused-optimizer", type=int, default=0, choices=(0, 1),
                     help="SGD slices inside backward, behind each group's / bucket's gradients")
     ap.add_argument("--distinct-batches", type=int, default=4)

@@ -64,7 +64,7 @@ class TrainConfig:
     use_graph: bool = False                # capture the native train step in a hipGraph
     wgrad_overlap: bool = True             # weight-gradient kernels on a second HIP stream
     fused_optimizer: bool = False          # SGD slices inside backward (needs wgrad_overlap)
-    wgrad_group: int = 2                   # layers handed to that stream per cross-stream event
+    wgrad_group: int = 0                   # layers per hand-off to that stream; 0 = auto
 
     # --- data ---
     synthetic: bool = True
