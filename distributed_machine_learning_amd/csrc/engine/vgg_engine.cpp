@@ -416,6 +416,8 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     const Conv& last = convs_[nconv - 1];
     const uint16_t* fc_in = arena_ + (last.pool_after ? last.pool_off : last.out_off);
     const bool side = wgrad_overlap_;
+    wgrad_queue_.clear();       // (left-overs of a step that threw)
+    wgrad_sums_.n = 0;
     const bool fuse_opt = side && opt_.on;
     opt_applied_ = fuse_opt;
     int updated_above = nconv + 1;      // layers >= this already had their parameters updated
