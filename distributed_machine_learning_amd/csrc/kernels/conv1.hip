@@ -67,7 +67,12 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
     for (int i = 0; i < 2; ++i) {
         const int chunk = tid + 256 * i;
         const int r = chunk >> 3, c = chunk & 7;
-        *(uint4*)(sB + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = *(const uint4*)(w1 + r * 64 + c * 8);
+        // Output-channel order of the four 16-row MFMA tiles: row q of tile i holds channel
+        // 16*(q>>2) + 4*i + (q&3), so that a lane's accumulators (rows 4*lq .. 4*lq+3 of every
+        // tile) are the 16 CONSECUTIVE channels 16*lq .. 16*lq+15 of its pixel: the result
+        // leaves as two 16-byte stores per pixel and four lanes complete a 128-byte row.
+        const int ch = 16 * ((r & 15) >> 2) + 4 * (r >> 4) + (r & 3);
+        *(uint4*)(sB + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = *(const uint4*)(w1 + ch * 64 + c * 8);
     }
     __syncthreads();
 
@@ -117,8 +122,8 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    red[(wave * 2 + 0) * 64 + i * 16 + lq * 4 + c] = s1[i][c];
-                    red[(wave * 2 + 1) * 64 + i * 16 + lq * 4 + c] = s2[i][c];
+                    red[(wave * 2 + 0) * 64 + lq * 16 + i * 4 + c] = s1[i][c];
+                    red[(wave * 2 + 1) * 64 + lq * 16 + i * 4 + c] = s2[i][c];
                 }
         }
         __syncthreads();
@@ -129,24 +134,30 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
                 red[(2 * 2 + which) * 64 + col] + red[(3 * 2 + which) * 64 + col];
         }
     }
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b = *(const float4*)(bias + lq * 16 + q * 4);
+        bv[q * 4 + 0] = b.x; bv[q * 4 + 1] = b.y; bv[q * 4 + 2] = b.z; bv[q * 4 + 3] = b.w;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = blockIdx.x * 256 + wave * 64 + j * 16 + l15;
         if (m >= M) continue;
+        uint32_t o[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = i * 16 + lq * 4;
-            const float4 b = *(const float4*)(bias + n);
-            float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z,
-                  v3 = acc[i][j][3] + b.w;
+            float v0 = acc[i][j][0] + bv[i * 4 + 0], v1 = acc[i][j][1] + bv[i * 4 + 1],
+                  v2 = acc[i][j][2] + bv[i * 4 + 2], v3 = acc[i][j][3] + bv[i * 4 + 3];
             if (relu) {
                 v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
             }
-            uint2 o;
-            o.x = pack2(v0, v1);
-            o.y = pack2(v2, v3);
-            *(uint2*)(y + (size_t)m * 64 + n) = o;
+            o[2 * i] = pack2(v0, v1);
+            o[2 * i + 1] = pack2(v2, v3);
         }
+        uint16_t* dst = y + (size_t)m * 64 + lq * 16;
+        *(uint4*)dst = make_uint4(o[0], o[1], o[2], o[3]);
+        *(uint4*)(dst + 8) = make_uint4(o[4], o[5], o[6], o[7]);
     }
 }
 

@@ -101,6 +101,43 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 #define DML_W_AUX 0
 #endif
 
+// Output-channel order inside a wave's WTN-channel share of the weight tile.  An MFMA
+// accumulator gives lane group lq = lane >> 4 rows 4*lq .. 4*lq+3 of every 16-row tile; with
+// tile i / row q holding channel  lq*(4*TN) + 4*i + (q & 3)  those rows are 4*TN CONSECUTIVE
+// channels, so a pixel's result leaves in 16-byte stores and the four lane groups complete
+// whole 128-byte lines (with the natural order, row q = channel q, a lane's channels are 32
+// bytes apart and every store instruction touches 16 rows x 4 separate 8-byte pieces).
+// Only the global -> LDS row addresses and the epilogue's channel numbers know about it.
+template <int WTN>
+__device__ __forceinline__ int permuted_channel(int r) {
+    constexpr int TN = WTN / 16;
+    const int q = r & 15, i = (r % WTN) >> 4;
+    return (r / WTN) * WTN + (q >> 2) * (4 * TN) + 4 * i + (q & 3);
+}
+
+// One pixel's share of a lane's accumulators -> memory: TN float4 (split-K slabs) or TN packed
+// 4-channel groups, consecutive in memory (see permuted_channel), paired into 16-byte stores.
+template <int TN, int EPI>
+__device__ __forceinline__ void store_lane_channels(const f32x4 (&a)[TN], uint16_t* y,
+                                                    const float* bias, const uint16_t* mask,
+                                                    size_t off, int n) {
+    uint32_t o[2 * TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const float4 v = epilogue4(a[i], EPI, bias, n + 4 * i, mask, off + 4 * i);
+        o[2 * i] = pack2(v.x, v.y);
+        o[2 * i + 1] = pack2(v.z, v.w);
+    }
+    if constexpr (TN % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < TN; i += 2)
+            *(uint4*)(y + off + 4 * i) = make_uint4(o[2 * i], o[2 * i + 1], o[2 * i + 2], o[2 * i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) *(uint2*)(y + off + 4 * i) = make_uint2(o[2 * i], o[2 * i + 1]);
+    }
+}
+
 // PM ("position-major") tiling: the BM rows of a tile are BM consecutive IMAGES at ONE
 // spatial position instead of BM consecutive NHWC pixels.  Whether a tap falls into the
 // padding then is the same for every row of the tile, so padded taps are skipped as whole K
@@ -195,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int r = wave * (BN / NW) + i * 8 + lrow;
-        w_off[i] = ((n0 + r) * 9 * C + ((slot ^ ((r >> 1) & 7)) << 3)) * 2;
+        w_off[i] = ((n0 + permuted_channel<WTN>(r)) * 9 * C + ((slot ^ ((r >> 1) & 7)) << 3)) * 2;
     }
     // The pixel descriptor starts (hw + 1) pixels BEFORE the tensor so that the scalar offset
     // (tap shift + that bias) is never negative; lanes whose tap is padding, or whose row is
@@ -336,7 +373,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int col = wn * WTN + i * 16 + lq * 4 + c;
+                    const int col = wn * WTN + lq * 4 * TN + 4 * i + c;
                     red[(wm * 2 + 0) * BN + col] = s1[i][c];
                     red[(wm * 2 + 1) * BN + col] = s2[i][c];
                 }
@@ -351,26 +388,26 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
         }
     }
 
-    // ---- epilogue: D[n][m]; lane holds n = nb + 4*lq + {0..3}, m = mb + l15
+    // ---- epilogue: lane holds pixel m = mb + l15 and its 4*TN consecutive channels
+    // n0 + wn*WTN + lq*4*TN + {0 .. 4*TN-1}, tile i contributing channels 4*i .. 4*i+3 of those
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int row = wm * WTM + j * 16 + l15;
         const int m = PM ? (img0 + row) * P + pos : m0 + row;
         if (PM ? (img0 + row >= p.batch) : (m >= p.M)) continue;
+        const int n = n0 + wn * WTN + lq * 4 * TN;
+        const size_t off = (size_t)m * p.N + n;
+        if (SPLIT) {
+            float* dst = p.slab + (size_t)blockIdx.y * p.M * p.N + off;
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int n = n0 + wn * WTN + i * 16 + lq * 4;
-            const size_t off = (size_t)m * p.N + n;
-            if (SPLIT) {
-                float* dst = p.slab + (size_t)blockIdx.y * p.M * p.N + off;
-                *(float4*)dst = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            } else {
-                const float4 v = epilogue4(acc[i][j], EPI, p.bias, n, p.mask, off);
-                uint2 o;
-                o.x = pack2(v.x, v.y);
-                o.y = pack2(v.z, v.w);
-                *(uint2*)(p.y + off) = o;
-            }
+            for (int i = 0; i < TN; ++i)
+                *(float4*)(dst + 4 * i) =
+                    float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        } else {
+            f32x4 a[TN];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) a[i] = acc[i][j];
+            store_lane_channels<TN, EPI>(a, p.y, p.bias, p.mask, off, n);
         }
     }
 }
@@ -608,7 +645,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(IgemmArgs p) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int r = wave * (BN / NW) + i * 8 + lrow;
-        w_off[i] = ((n0 + r) * 9 * C + ((slot ^ ((r >> 1) & 7)) << 3)) * 2;
+        w_off[i] = ((n0 + permuted_channel<WTN>(r)) * 9 * C + ((slot ^ ((r >> 1) & 7)) << 3)) * 2;
     }
     int p_off[P_IT];        // byte offset of this lane's chunk of patch row (group, lrow), chunk 0
 #pragma unroll
@@ -757,7 +794,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(IgemmArgs p) {
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int col = wn * WTN + i * 16 + lq * 4 + c;
+                    const int col = wn * WTN + lq * 4 * TN + 4 * i + c;
                     red[(wm * 2 + 0) * BN + col] = s1[i][c];
                     red[(wm * 2 + 1) * BN + col] = s2[i][c];
                 }
@@ -776,16 +813,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(IgemmArgs p) {
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + wm * WTM + j * 16 + l15;
         if (m >= p.M) continue;
+        const int n = n0 + wn * WTN + lq * 4 * TN;
+        f32x4 a[TN];
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int n = n0 + wn * WTN + i * 16 + lq * 4;
-            const size_t off = (size_t)m * p.N + n;
-            const float4 v = epilogue4(acc[i][j], EPI, p.bias, n, p.mask, off);
-            uint2 o;
-            o.x = pack2(v.x, v.y);
-            o.y = pack2(v.z, v.w);
-            *(uint2*)(p.y + off) = o;
-        }
+        for (int i = 0; i < TN; ++i) a[i] = acc[i][j];
+        store_lane_channels<TN, EPI>(a, p.y, p.bias, p.mask, (size_t)m * p.N + n, n);
     }
 }
 
