@@ -262,163 +262,176 @@ void softmax_xent(const float* logits, const int64_t* target, float* loss_sum, f
 
 // ------------------------------------------------ fused classifier step for training
 // nn.Linear(512, 10) + nn.CrossEntropyLoss forward and backward in two launches
-// (/root/reference/part1/model.py:40,45 and /root/reference/part1/main.py:43-44): the first
-// kernel gives every wave a few rows - logits, softmax, loss, dlogits, dx and the partial
-// dW / db, all from one 16-byte load of the row per lane; a block folds its four waves in
-// LDS - the second sums the per-block partials.  No atomics, no memsets: the result is bit-reproducible.
+// (/root/reference/part1/model.py:40,45 and /root/reference/part1/main.py:43-44).
+//   rows kernel : one wave per batch row, one 16-byte load of the row per lane - logits,
+//                 softmax, the row's loss term, dlogits and dx (everything that needs only
+//                 its own row)
+//   grads kernel: dW = dlogits^T x, db, loss and accuracy - reductions over the batch; a
+//                 block owns 32 feature columns, its 8 row groups are folded in LDS in a fixed order
+// No atomics, no memsets: the result is bit-reproducible.
 constexpr int kFcMaxClasses = 16;
-constexpr int kFcRowsPerWave = 2;
-constexpr int kFcRowsPerBlock = 4 * kFcRowsPerWave;
+constexpr int kFcCols = 32;          // feature columns per block of the grads kernel
+constexpr int kFcGroups = 8;         // row groups per block (256 threads = 32 columns x 8 groups)
 
-__global__ __launch_bounds__(256) void fc_train_kernel(
+__global__ __launch_bounds__(256) void fc_train_rows_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const int64_t* __restrict__ target, float* __restrict__ logits, uint16_t* __restrict__ dx,
-    float* __restrict__ part, int batch, int k_dim, int n, float inv_batch) {
-    __shared__ float red[kFcMaxClasses * 512 + 4 * (kFcMaxClasses + 2)];
+    float* __restrict__ dlogits, float* __restrict__ rowstat, int batch, int k_dim, int n,
+    float inv_batch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t pstride = (size_t)n * k_dim + 2 * kFcMaxClasses;
-    float* my = part + (size_t)blockIdx.x * pstride;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= batch) return;
     const int kb = lane * 8;                 // k_dim == 512: one 16-byte chunk per lane
-    float loss_acc = 0.f, ok_acc = 0.f, db_acc = 0.f;      // lane c < n accumulates db[c]
-    // every global load of the wave is issued up front: its rows, their targets, the weights
-    uint4 xraw[kFcRowsPerWave];
-    int tgt[kFcRowsPerWave];
+    const uint4 xraw = *(const uint4*)(x + (size_t)row * k_dim + kb);
+    const int t = (int)target[row];
+    float wreg[kFcMaxClasses][8];
 #pragma unroll
-    for (int rr = 0; rr < kFcRowsPerWave; ++rr) {
-        const int row = (blockIdx.x * 4 + wave) * kFcRowsPerWave + rr;
-        const int rc = row < batch ? row : batch - 1;
-        xraw[rr] = *(const uint4*)(x + (size_t)rc * k_dim + kb);
-        tgt[rr] = (int)target[rc];
-    }
-    float wreg[kFcMaxClasses][8], dwacc[kFcMaxClasses][8];
-#pragma unroll
-    for (int c = 0; c < kFcMaxClasses; ++c) {
+    for (int c = 0; c < kFcMaxClasses; ++c)
         if (c < n) {
             const float4 a = *(const float4*)(w + (size_t)c * k_dim + kb);
             const float4 b = *(const float4*)(w + (size_t)c * k_dim + kb + 4);
             wreg[c][0] = a.x; wreg[c][1] = a.y; wreg[c][2] = a.z; wreg[c][3] = a.w;
             wreg[c][4] = b.x; wreg[c][5] = b.y; wreg[c][6] = b.z; wreg[c][7] = b.w;
         }
+    float xv[8];
+    unpack8(xraw, xv);
+    float lg[kFcMaxClasses];
+    float mx = -3.0e38f;
+    int arg = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dwacc[c][i] = 0.f;
-    }
+    for (int c = 0; c < kFcMaxClasses; ++c) {
+        lg[c] = 0.f;
+        if (c < n) {
+            float p = 0.f;
 #pragma unroll
-    for (int rr = 0; rr < kFcRowsPerWave; ++rr) {
-        const int row = (blockIdx.x * 4 + wave) * kFcRowsPerWave + rr;
-        if (row >= batch) break;
-        float xv[8];
-        unpack8(xraw[rr], xv);
-        const int t = tgt[rr];
-        float lg[kFcMaxClasses];
-        float mx = -3.0e38f;
-        int arg = 0;
-#pragma unroll
-        for (int c = 0; c < kFcMaxClasses; ++c) {
-            lg[c] = 0.f;
-            if (c < n) {
-                float p = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) p += xv[i] * wreg[c][i];
-                lg[c] = wave_sum_dpp(p) + bias[c];
-                if (lg[c] > mx) { mx = lg[c]; arg = c; }
-            }
+            for (int i = 0; i < 8; ++i) p += xv[i] * wreg[c][i];
+            lg[c] = wave_sum_dpp(p) + bias[c];
+            if (lg[c] > mx) { mx = lg[c]; arg = c; }
         }
-        float se = 0.f;
+    }
+    float se = 0.f;
 #pragma unroll
-        for (int c = 0; c < kFcMaxClasses; ++c)
-            if (c < n) se += __expf(lg[c] - mx);
-        const float inv = 1.f / se;
-        float lt = 0.f, o[8];
+    for (int c = 0; c < kFcMaxClasses; ++c)
+        if (c < n) se += __expf(lg[c] - mx);
+    const float inv = 1.f / se;
+    float lt = 0.f, o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
 #pragma unroll
-        for (int c = 0; c < kFcMaxClasses; ++c) {
-            if (c < n) {
-                if (c == t) lt = lg[c];
-                const float dl = (__expf(lg[c] - mx) * inv - (c == t ? 1.f : 0.f)) * inv_batch;
+    for (int c = 0; c < kFcMaxClasses; ++c) {
+        float dl = 0.f;
+        if (c < n) {
+            if (c == t) lt = lg[c];
+            dl = (__expf(lg[c] - mx) * inv - (c == t ? 1.f : 0.f)) * inv_batch;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    o[i] += dl * wreg[c][i];
-                    dwacc[c][i] += dl * xv[i];
-                }
-                if (lane == c) {
-                    logits[(size_t)row * n + c] = lg[c];
-                    db_acc += dl;
-                }
-            }
+            for (int i = 0; i < 8; ++i) o[i] += dl * wreg[c][i];
+            if (lane == c) logits[(size_t)row * n + c] = lg[c];
         }
-        loss_acc += (mx + __logf(se) - lt) * inv_batch;
-        ok_acc += (arg == t) ? 1.f : 0.f;
-        if (dx) *(uint4*)(dx + (size_t)row * k_dim + kb) = pack8(o);
+        if (lane == c) dlogits[(size_t)row * kFcMaxClasses + c] = dl;     // zero beyond n
     }
-    // block partial: the four waves add their dW into LDS one after the other
-    float* tails = red + kFcMaxClasses * 512;
-    for (int turn = 0; turn < 4; ++turn) {
-        if (wave == turn) {
-#pragma unroll
-            for (int c = 0; c < kFcMaxClasses; ++c) {
-                if (c < n) {
-                    float4* dst = (float4*)(red + c * 512 + kb);
-                    float4 a = {dwacc[c][0], dwacc[c][1], dwacc[c][2], dwacc[c][3]};
-                    float4 b = {dwacc[c][4], dwacc[c][5], dwacc[c][6], dwacc[c][7]};
-                    if (turn > 0) {
-                        const float4 pa = dst[0], pb = dst[1];
-                        a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
-                        b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
-                    }
-                    dst[0] = a;
-                    dst[1] = b;
-                }
-            }
-            if (lane < kFcMaxClasses) tails[wave * (kFcMaxClasses + 2) + lane] = lane < n ? db_acc : 0.f;
-            if (lane == 0) {
-                tails[wave * (kFcMaxClasses + 2) + kFcMaxClasses] = loss_acc;
-                tails[wave * (kFcMaxClasses + 2) + kFcMaxClasses + 1] = ok_acc;
-            }
-        }
-        __syncthreads();
+    if (lane == 0) {
+        rowstat[(size_t)row * 2] = (mx + __logf(se) - lt) * inv_batch;
+        rowstat[(size_t)row * 2 + 1] = (arg == t) ? 1.f : 0.f;
     }
-    for (int i = threadIdx.x; i < n * 512 / 4; i += 256)
-        ((float4*)my)[i] = ((const float4*)red)[i];
-    if (threadIdx.x < kFcMaxClasses + 2) {
-        const int q = threadIdx.x;
-        const float v = tails[q] + tails[(kFcMaxClasses + 2) + q] + tails[2 * (kFcMaxClasses + 2) + q] +
-                        tails[3 * (kFcMaxClasses + 2) + q];
-        my[(size_t)n * k_dim + (q < kFcMaxClasses ? q : q)] = v;
-    }
+    if (dx) *(uint4*)(dx + (size_t)row * k_dim + kb) = pack8(o);
 }
 
-__global__ __launch_bounds__(256) void fc_train_finish_kernel(
-    const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
-    float* __restrict__ loss, int32_t* __restrict__ correct, int parts, int k_dim, int n) {
-    const size_t pstride = (size_t)n * k_dim + 2 * kFcMaxClasses;
-    const int total = n * k_dim;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) {
-        float s = 0.f;
-        int q = 0;
-        for (; q + 7 < parts; q += 8) {
-            float v[8];
+__global__ __launch_bounds__(256) void fc_train_grads_kernel(
+    const uint16_t* __restrict__ x, const float* __restrict__ dlogits,
+    const float* __restrict__ rowstat, float* __restrict__ dw, float* __restrict__ db,
+    float* __restrict__ loss, int32_t* __restrict__ correct, int batch, int k_dim, int n) {
+    // The kernel is a latency chain, not a bandwidth problem: 256 rows of its 32 columns and
+    // of dlogits are staged in LDS with every global load issued up front (one round trip per
+    // 256 rows), and the sums run out of LDS.
+    constexpr int kTile = 256;
+    __shared__ __attribute__((aligned(16))) uint16_t sx[kTile][kFcCols];
+    __shared__ __attribute__((aligned(16))) float sd[kTile][kFcMaxClasses];
+    __shared__ float2 sr[kTile];
+    __shared__ float red[kFcGroups][kFcMaxClasses][kFcCols + 1];
+    const int col = threadIdx.x % kFcCols, grp = threadIdx.x / kFcCols;
+    const int f0 = blockIdx.x * kFcCols;
+    // batch sums of dlogits (db, block 0) and of the loss terms / hits (block 1) come out of
+    // the same staged tiles: thread = (column c16, one of 16 row groups g16)
+    const int c16 = threadIdx.x % 16, g16 = threadIdx.x / 16;
+    float tail = 0.f;
+    float acc[kFcMaxClasses];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(q + u) * pstride + i];
+    for (int c = 0; c < kFcMaxClasses; ++c) acc[c] = 0.f;
+    for (int base = 0; base < batch; base += kTile) {
+        uint4 xr[4];
+        float4 dr[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+        for (int i = 0; i < 4; ++i) {
+            const int id = threadIdx.x + 256 * i;
+            const int rx = base + (id >> 2), rd = base + (id >> 2);
+            xr[i] = rx < batch ? *(const uint4*)(x + (size_t)rx * k_dim + f0 + (id & 3) * 8)
+                               : make_uint4(0, 0, 0, 0);
+            dr[i] = rd < batch ? *(const float4*)(dlogits + (size_t)rd * kFcMaxClasses + (id & 3) * 4)
+                               : float4{0.f, 0.f, 0.f, 0.f};
         }
-        for (; q < parts; ++q) s += part[(size_t)q * pstride + i];
-        dw[i] = s;
+        const int rs = base + (int)threadIdx.x;
+        const float2 st = rs < batch ? *(const float2*)(rowstat + (size_t)rs * 2) : float2{0.f, 0.f};
+        if (base) __syncthreads();          // the previous tile has been consumed
+        sr[threadIdx.x] = st;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = threadIdx.x + 256 * i;
+            *(uint4*)(&sx[id >> 2][(id & 3) * 8]) = xr[i];
+            *(float4*)(&sd[id >> 2][(id & 3) * 4]) = dr[i];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = grp; r < kTile; r += kFcGroups) {
+            const float xv = bf16_bits_to_float(sx[r][col]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 d = *(const float4*)(&sd[r][4 * q]);
+                acc[4 * q + 0] += d.x * xv;
+                acc[4 * q + 1] += d.y * xv;
+                acc[4 * q + 2] += d.z * xv;
+                acc[4 * q + 3] += d.w * xv;
+            }
+        }
+        if (blockIdx.x == 0) {
+            for (int r = g16; r < kTile; r += 16) tail += sd[r][c16];
+        } else if (blockIdx.x == 1 && c16 < 2) {
+            for (int r = g16; r < kTile; r += 16) tail += c16 ? sr[r].y : sr[r].x;
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x < kFcMaxClasses + 2) {
+#pragma unroll
+    for (int c = 0; c < kFcMaxClasses; ++c) red[grp][c][col] = acc[c];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < n * kFcCols; idx += 256) {
+        const int c = idx / kFcCols, cc = idx % kFcCols;
         float s = 0.f;
-        for (int q = 0; q < parts; ++q) s += part[(size_t)q * pstride + total + threadIdx.x];
-        if (threadIdx.x < n) db[threadIdx.x] = s;
-        else if (threadIdx.x == kFcMaxClasses) loss[0] = s;
-        else if (threadIdx.x == kFcMaxClasses + 1 && correct) correct[0] = (int)(s + 0.5f);
+#pragma unroll
+        for (int g = 0; g < kFcGroups; ++g) s += red[g][c][cc];
+        dw[(size_t)c * k_dim + f0 + cc] = s;
+    }
+    if (blockIdx.x < 2) {
+        __syncthreads();
+        const int width = blockIdx.x == 0 ? kFcMaxClasses : 2;
+        float* flat = &red[0][0][0];
+        flat[g16 * 16 + c16] = tail;
+        __syncthreads();
+        if ((int)threadIdx.x < width) {
+            float tsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tsum += flat[q * 16 + threadIdx.x];
+            if (blockIdx.x == 0) {
+                if ((int)threadIdx.x < n) db[threadIdx.x] = tsum;
+            } else if (threadIdx.x == 0) {
+                loss[0] = tsum;
+            } else if (correct) {
+                correct[0] = (int)(tsum + 0.5f);
+            }
+        }
     }
 }
 
 size_t fc_train_workspace_elems(int batch, int in_features, int out_features) {
-    const int blocks = (batch + kFcRowsPerBlock - 1) / kFcRowsPerBlock;
-    return (size_t)blocks * ((size_t)out_features * in_features + 2 * kFcMaxClasses);
+    (void)in_features; (void)out_features;
+    return (size_t)batch * (kFcMaxClasses + 2);      // dlogits [batch][16] + (loss term, hit) per row
 }
 
 void fc_train(const bf16_raw* x, const float* w, const float* bias, const int64_t* target,
@@ -429,12 +442,14 @@ void fc_train(const bf16_raw* x, const float* w, const float* bias, const int64_
     if (out_features < 1 || out_features > kFcMaxClasses)
         throw std::invalid_argument("fc_train: 1..16 classes");
     if (batch <= 0) return;
-    const int blocks = (batch + kFcRowsPerBlock - 1) / kFcRowsPerBlock;
-    hipLaunchKernelGGL(fc_train_kernel, dim3(blocks), dim3(256), 0, stream, x, w, bias, target,
-                       logits, dx, ws, batch, in_features, out_features, 1.0f / (float)batch);
-    const int total = out_features * in_features;
-    hipLaunchKernelGGL(fc_train_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
-                       (const float*)ws, dw, db, loss, correct, blocks, in_features, out_features);
+    float* dlogits = ws;
+    float* rowstat = ws + (size_t)batch * kFcMaxClasses;
+    hipLaunchKernelGGL(fc_train_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, x, w, bias,
+                       target, logits, dx, dlogits, rowstat, batch, in_features, out_features,
+                       1.0f / (float)batch);
+    hipLaunchKernelGGL(fc_train_grads_kernel, dim3(in_features / kFcCols), dim3(256), 0, stream, x,
+                       (const float*)dlogits, (const float*)rowstat, dw, db, loss, correct, batch,
+                       in_features, out_features);
 }
 
 }  // namespace dml
