@@ -312,7 +312,6 @@ void VggEngine::refresh_weights(hipStream_t stream) {
     // Full refresh: needed when the master weights were written from outside (initialisation,
     // load_state_dict); during training the optimizer kernel keeps the shadow current.
     cast_f32_to_bf16(params_, arena_ + shadow_off_, param_elems_, stream);
-    repack_conv1_weights(params_ + convs_[0].w_off, arena_ + w1_off_, stream);
     repack_all(stream);
 }
 
@@ -331,7 +330,10 @@ std::vector<std::vector<long long>> VggEngine::layer_table() const {
 }
 
 void VggEngine::repack_all(hipStream_t stream) {
-    // backward-data weight layout for every conv after the first, 16 layers per launch
+    // backward-data weight layout for every conv after the first, 16 layers per launch; the
+    // first layer's padded bf16 layout rides in the first launch
+    const float* c1 = params_ + convs_[0].w_off;
+    if (convs_.size() == 1) repack_conv1_weights(c1, arena_ + w1_off_, stream);
     RepackJobs jobs;
     for (size_t i = 1; i < convs_.size(); ++i) {
         const Conv& c = convs_[i];
@@ -340,7 +342,8 @@ void VggEngine::repack_all(hipStream_t stream) {
         jobs.src_off[jobs.n] = shadow_off_ + c.w_off;
         jobs.dst_off[jobs.n] = c.wd_off;
         if (++jobs.n == RepackJobs::kMax || i + 1 == convs_.size()) {
-            repack_dgrad_weights_batch(arena_, arena_, jobs, stream);
+            repack_dgrad_weights_batch(arena_, arena_, jobs, stream, c1, arena_ + w1_off_);
+            c1 = nullptr;
             jobs.n = 0;
         }
     }
@@ -543,7 +546,6 @@ void VggEngine::optimizer_step(float lr, float momentum, float weight_decay, flo
         sgd_momentum(params_, grads_, mom_, arena_ + shadow_off_, param_elems_, lr, momentum,
                      weight_decay, grad_scale, false, stream);
     }
-    repack_conv1_weights(params_ + convs_[0].w_off, arena_ + w1_off_, stream);
     repack_all(stream);
 }
 

@@ -104,7 +104,8 @@ struct RepackJobs {
     int tile_start[kMax + 1];     // filled by the launcher
 };
 void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, RepackJobs jobs,
-                                hipStream_t stream);
+                                hipStream_t stream, const float* conv1_w = nullptr,
+                                bf16_raw* conv1_w1 = nullptr);
 // w1[64][64] bf16 (k = tap*4 + c) from master fp32 [64][9][3]
 void repack_conv1_weights(const float* w, bf16_raw* w1, hipStream_t stream);
 

@@ -299,22 +299,31 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
 }
 
 // dw[co][tap][c] = sum_blocks slab[b][co][tap*4+c] (c < 3), db[co] = sum_blocks slab[b][co][36].
-// Grid: 40 blocks of 64 outputs; 4 lanes per output each fold a quarter of the slab rows.
+// A latency chain, not a bandwidth problem (5 MB): 160 blocks of 16 outputs x 16 parts; a part
+// folds every 16th slab row with eight independent loads in flight, the parts meet in LDS.
 __global__ __launch_bounds__(256) void conv1_wgrad_finish_kernel(const float* __restrict__ slab,
                                                                  float* __restrict__ dw,
                                                                  float* __restrict__ db,
                                                                  int nblocks) {
-    __shared__ float red[4][64];
-    const int o = blockIdx.x * 64 + (threadIdx.x & 63);      // 0 .. 2559 = co * 40 + k
-    const int part = threadIdx.x >> 6;
+    __shared__ float red[16][17];
+    const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + col;                     // 0 .. 2559 = co * 40 + k
     float s = 0.f;
-#pragma unroll 8
-    for (int b = part; b < nblocks; b += 4) s += slab[(size_t)b * 2560 + o];
-    red[part][threadIdx.x & 63] = s;
+    int b = part;
+    for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(b + 16 * u) * 2560 + o];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nblocks; b += 16) s += slab[(size_t)b * 2560 + o];
+    red[part][col] = s;
     __syncthreads();
     if (part == 0) {
-        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
-                        red[3][threadIdx.x];
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][col];
         const int co = o / 40, k = o % 40;
         const int tap = k >> 2, c = k & 3;
         if (tap < 9 && c < 3) dw[co * 27 + tap * 3 + c] = v;
@@ -347,7 +356,7 @@ void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, in
     int spb;
     const int blocks = conv1_wgrad_blocks(M, &spb);
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, ws, M, spb);
-    hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(40), dim3(256), 0, stream,
+    hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(160), dim3(256), 0, stream,
                        (const float*)ws, dw, db, blocks);
 }
 

@@ -340,11 +340,32 @@ void repack_dgrad_weights(const bf16_raw* wf, bf16_raw* wd, int cout, int cin, h
                        wd, cout, cin);
 }
 
-// All layers of a model in one launch: block -> (layer, ci tile, co tile, tap).
+void repack_conv1_weights(const float* w, bf16_raw* w1, hipStream_t stream);
+
+// All layers of a model in one launch: block -> (layer, ci tile, co tile, tap); optionally 16
+// more blocks that lay out the first layer's weights (fp32 [64][27] -> bf16 [64][64], K padded).
+__device__ __forceinline__ void repack_conv1_block(const float* __restrict__ w,
+                                                   uint16_t* __restrict__ w1, int block) {
+    const int idx = block * 256 + threadIdx.x;      // 64 * 64
+    if (idx >= 4096) return;
+    const int co = idx >> 6, k = idx & 63;
+    const int tap = k >> 2, c = k & 3;
+    float v = 0.f;
+    if (tap < 9 && c < 3) v = w[co * 27 + tap * 3 + c];
+    w1[idx] = float_to_bf16_bits(v);
+}
+
 __global__ __launch_bounds__(256) void repack_dgrad_batch_kernel(const uint16_t* __restrict__ src,
                                                                  uint16_t* __restrict__ dst,
-                                                                 RepackJobs jobs) {
+                                                                 RepackJobs jobs,
+                                                                 const float* __restrict__ conv1_w,
+                                                                 uint16_t* __restrict__ conv1_w1) {
     __shared__ uint16_t tile[64][66];
+    const int total = jobs.tile_start[jobs.n];
+    if ((int)blockIdx.x >= total) {         // the 16 trailing blocks: first-layer weight layout
+        repack_conv1_block(conv1_w, conv1_w1, blockIdx.x - total);
+        return;
+    }
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.tile_start[j + 1]) ++j;
     int t = blockIdx.x - jobs.tile_start[j];
@@ -357,8 +378,11 @@ __global__ __launch_bounds__(256) void repack_dgrad_batch_kernel(const uint16_t*
 }
 
 void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, RepackJobs jobs,
-                                hipStream_t stream) {
-    if (jobs.n <= 0) return;
+                                hipStream_t stream, const float* conv1_w, bf16_raw* conv1_w1) {
+    if (jobs.n <= 0) {
+        if (conv1_w) repack_conv1_weights(conv1_w, conv1_w1, stream);
+        return;
+    }
     if (jobs.n > RepackJobs::kMax) throw std::invalid_argument("repack batch: too many layers");
     int total = 0;
     for (int j = 0; j < jobs.n; ++j) {
@@ -368,19 +392,13 @@ void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, Re
         total += (jobs.cin[j] / 64) * (jobs.cout[j] / 64) * 9;
     }
     jobs.tile_start[jobs.n] = total;
-    hipLaunchKernelGGL(repack_dgrad_batch_kernel, dim3(total), dim3(256), 0, stream, src_base,
-                       dst_base, jobs);
+    hipLaunchKernelGGL(repack_dgrad_batch_kernel, dim3(total + (conv1_w ? 16 : 0)), dim3(256), 0,
+                       stream, src_base, dst_base, jobs, conv1_w, conv1_w1);
 }
 
 __global__ __launch_bounds__(256) void repack_conv1_kernel(const float* __restrict__ w,
                                                            uint16_t* __restrict__ w1) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // 64 * 64
-    if (idx >= 4096) return;
-    const int co = idx >> 6, k = idx & 63;
-    const int tap = k >> 2, c = k & 3;
-    float v = 0.f;
-    if (tap < 9 && c < 3) v = w[co * 27 + tap * 3 + c];
-    w1[idx] = float_to_bf16_bits(v);
+    repack_conv1_block(w, w1, blockIdx.x);
 }
 
 void repack_conv1_weights(const float* w, bf16_raw* w1, hipStream_t stream) {
