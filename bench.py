@@ -48,14 +48,14 @@ def parse():
     ap.add_argument("--backend", choices=("native", "torch"), default="native")
     ap.add_argument("--dtype", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU)")
-    ap.add_argument("--bucket-cap-mb", type=float, default=24.0,
-                    help="gradient bucket size.  24 MiB (first bucket included) cuts VGG-11's "
-                         "37 MB of gradients into {fc1, conv8, conv7, conv6} - ready a third of "
-                         "the way into backward - and {conv5 .. conv1}, which --tail-bucket-cap-mb "
-                         "splits again.  Every bucket costs ~13 us of compute-stream time in "
-                         "cross-stream hand-offs (measured at one rank: ~3 us for the event "
-                         "record, ~10 us for the second queue's wait / record), so few large "
-                         "buckets beat many small ones on a ~0.8 ms step")
+    ap.add_argument("--bucket-cap-mb", type=float, default=10.0,
+                    help="gradient bucket size.  10 MiB (first bucket included) cuts VGG-11's "
+                         "37 MB of gradients into {fc1, conv8, conv7} - on the wire a quarter of "
+                         "the way into backward -, {conv6, conv5} and {conv4 .. conv1}, which "
+                         "--tail-bucket-cap-mb splits again.  Buckets leave from the weight-"
+                         "gradient stream, so an extra bucket costs the compute stream nothing "
+                         "(measured at one rank: 2 .. 24 MiB caps are within 2 %% of each other); "
+                         "smaller buckets put the first bytes on the wire earlier")
     ap.add_argument("--first-bucket-cap-mb", type=float, default=None,
                     help="defaults to --bucket-cap-mb")
     ap.add_argument("--tail-bucket-cap-mb", type=float, default=1.0,
