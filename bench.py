@@ -63,6 +63,8 @@ def parse():
                          "final wgrad ({conv4, conv3} then hide behind conv2/conv1 backward and "
                          "only {conv2, conv1}, 0.3 MB, is exposed)")
     ap.add_argument("--serialize-streams", action="store_true")
+    ap.add_argument("--compute-stream", choices=("default", "new"), default="default",
+                    help="run the step on torch's default (null) stream or on a created one")
     ap.add_argument("--wgrad-overlap", type=int, default=1, choices=(0, 1),
                     help="weight-gradient kernels on a second HIP stream")
     ap.add_argument("--wgrad-group", type=int, default=0, help="0 = auto")
@@ -92,6 +94,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X GPU")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    if ns.compute_stream == "new":
+        torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
     from distributed_machine_learning_amd.data import synthetic_cifar
     from distributed_machine_learning_amd.data.transforms import BatchTransform
