@@ -92,6 +92,16 @@ PYBIND11_MODULE(_C, m) {
                     batch, ptr<float>(ws), st(stream));
     });
     m.def("conv1_wgrad_workspace_elems", &conv1_wgrad_workspace_elems);
+    m.def("conv1_wgrad_bn_pool", [](uintptr_t x, uintptr_t pre, uintptr_t dyp, uintptr_t gamma,
+                                    uintptr_t beta, uintptr_t mean, uintptr_t rstd, uintptr_t dgamma,
+                                    uintptr_t dbeta, uintptr_t dw, int batch, uintptr_t ws,
+                                    uintptr_t s) {
+        conv1_wgrad_bn_pool(ptr<const bf16_raw>(x), ptr<const bf16_raw>(pre),
+                            ptr<const bf16_raw>(dyp), ptr<const float>(gamma), ptr<const float>(beta),
+                            ptr<const float>(mean), ptr<const float>(rstd),
+                            ptr<const float>(dgamma), ptr<const float>(dbeta), ptr<float>(dw), batch,
+                            ptr<float>(ws), st(s));
+    });
     m.def("column_reduce_workspace_elems", &bn_workspace_elems);
     m.def("repack_dgrad_weights", [](uintptr_t wf, uintptr_t wd, int cout, int cin, uintptr_t s) {
         repack_dgrad_weights(ptr<const bf16_raw>(wf), ptr<bf16_raw>(wd), cout, cin, st(s));

@@ -230,9 +230,14 @@ void VggEngine::sgd_slice(size_t begin, size_t end, hipStream_t stream) {
 
 void VggEngine::join_wgrad_stream(hipStream_t stream) {
     if (!side_busy_) return;
-    check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
+    // side_done_ was recorded right behind the side stream's last launch (see backward), so
+    // that it has usually fired by now and this wait costs the main stream nothing; recording
+    // it here would send a fresh marker through the other queue (~10 us) on the critical path
+    if (!side_done_recorded_)
+        check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
     check_hip(hipStreamWaitEvent(stream, side_done_, 0), "hipStreamWaitEvent(side done)");
     side_busy_ = false;
+    side_done_recorded_ = false;
 }
 
 // Weight (and, without BatchNorm, bias) gradient of one conv layer after the first.
@@ -421,6 +426,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     const bool side = wgrad_overlap_;
     wgrad_queue_.clear();       // (left-overs of a step that threw)
     wgrad_sums_.n = 0;
+    side_done_recorded_ = false;
     const bool fuse_opt = side && opt_.on;
     opt_applied_ = fuse_opt;
     int updated_above = nconv + 1;      // layers >= this already had their parameters updated
@@ -451,8 +457,11 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
         const Conv& c = convs_[i];
         const int rows = batch * c.hw * c.hw;
         uint16_t* g = arena_ + c.gout_off;       // dL/d(conv output), ReLU mask applied
+        // first layer under BatchNorm + pool: its weight-gradient kernel forms g on the fly
+        const bool g_on_the_fly = i == 0 && bn_ && c.pool_after;
         if (bn_ && c.pool_after)
-            bn_relu_pool_bwd(arena_ + c.pre_off, transit, g, params_ + c.gamma_off,
+            bn_relu_pool_bwd(arena_ + c.pre_off, transit, g_on_the_fly ? nullptr : g,
+                             params_ + c.gamma_off,
                              params_ + c.beta_off, ws_ + c.save_off, ws_ + c.save_off + c.cout,
                              grads_ + c.gamma_off, grads_ + c.beta_off, ws_ + stats_off_, batch,
                              c.hw, c.cout, stream);
@@ -463,7 +472,12 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             bn_relu_bwd(arena_ + c.pre_off, transit, g, params_ + c.gamma_off, params_ + c.beta_off,
                         ws_ + c.save_off, ws_ + c.save_off + c.cout, grads_ + c.gamma_off,
                         grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream);
-        if (i == 0) {
+        if (g_on_the_fly) {
+            conv1_wgrad_bn_pool(x, arena_ + c.pre_off, transit, params_ + c.gamma_off,
+                                params_ + c.beta_off, ws_ + c.save_off, ws_ + c.save_off + c.cout,
+                                grads_ + c.gamma_off, grads_ + c.beta_off, grads_ + c.w_off, batch,
+                                slab, stream);
+        } else if (i == 0) {
             // shares the split-K slab with the input-gradient kernels: always on the main stream
             conv1_wgrad(x, g, grads_ + c.w_off, bn_ ? nullptr : grads_ + c.b_off, batch, slab,
                         stream);
@@ -504,6 +518,10 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                 // the gradients of layers i.. (and the classifier) are final behind the sums
                 sgd_slice(layer_begin(i), layer_begin(updated_above), wgrad_stream_);
                 updated_above = i;
+            }
+            if (!reducer_ && i <= 1) {      // the side stream's last work of this step
+                check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
+                side_done_recorded_ = true;
             }
         }
         if (!side) fire_buckets(i, stream);

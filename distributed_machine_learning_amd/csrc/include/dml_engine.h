@@ -152,6 +152,7 @@ class VggEngine {
     std::vector<hipEvent_t> hand_off_;      // per layer: main-stream position the side stream waits for
     hipEvent_t side_done_ = nullptr;
     std::vector<int> wgrad_queue_;          // layers whose gradient is ready, wgrad not yet launched
+    bool side_done_recorded_ = false;
     bool side_busy_ = false;                // side-stream work the main stream has not waited for
     hipGraph_t graph_ = nullptr;
     hipGraphExec_t graph_exec_ = nullptr;

@@ -71,6 +71,13 @@ int conv1_fprop_stats_rows(int batch);     // rows of [2][64] floats written to 
 void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, int batch,
                  float* ws, hipStream_t stream);
 size_t conv1_wgrad_workspace_elems(int batch);
+// The same for a first layer followed by BatchNorm + ReLU + 2x2 max-pool, from the gradient of
+// the POOLED output: dL/d(conv output) is formed on the fly from the conv output `pre` and the
+// BatchNorm constants (dgamma / dbeta from bn_relu_pool_bwd with dx == nullptr) and never stored.
+void conv1_wgrad_bn_pool(const bf16_raw* x, const bf16_raw* pre, const bf16_raw* dy_pooled,
+                         const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_rstd, const float* dgamma, const float* dbeta, float* dw,
+                         int batch, float* ws, hipStream_t stream);
 
 // dw[cout][9][cin] (+)= sum_p dy[p][cout] * x[p (+) tap][cin]   (fp32).  The pixel range is
 // split over several blocks per tile.  Without `slab` the splits accumulate into `dw` with

@@ -405,11 +405,11 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
             const float rs = rstd[col];
             const float mrs = mean[col] * rs;
             ysc[k] = gamma[col] * rs;
-            ysh[k] = beta[col] - gamma[col] * mrs;
+            ysh[k] = __builtin_fmaf(-gamma[col], mrs, beta[col]);
             k1[k] = gamma[col] * rs;
             const float dg = dgamma[col] * inv_n, db = dbeta[col] * inv_n;
-            k2[k] = k1[k] * (db - mrs * dg);
-            k3[k] = k1[k] * rs * dg;
+            k2[k] = k1[k] * __builtin_fmaf(-mrs, dg, db);
+            k3[k] = (k1[k] * rs) * dg;
         }
     }
     for (; i < total8; i += stride) {
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
             const float gk = live ? k1[k] * g[k] : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                o[q][k] = (w == q ? gk : 0.f) - k2[k] - k3[k] * v[q][k];
+                o[q][k] = __builtin_fmaf(-k3[k], v[q][k], (w == q ? gk : 0.f) - k2[k]);
         }
         uint16_t* p = dx + ipix * c + cg * 8;
         *(uint4*)(p) = pack8(o[0]);
@@ -486,6 +486,7 @@ void bn_relu_pool_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const
                        gamma, beta, save_mean, save_rstd, ws, out_rows, c, pl.rows_per_block, geo);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
                        (const float*)ws, dgamma, dbeta, pl.blocks, c);
+    if (!dx) return;        // the caller's next kernel produces dx on the fly (conv1_wgrad_bn_pool)
     const size_t total8 = (size_t)out_rows * (c / 8);
     hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(apply_blocks(total8)), dim3(256), 0, stream,
                        x, dy, dx, gamma, beta, save_mean, save_rstd, (const float*)dgamma,

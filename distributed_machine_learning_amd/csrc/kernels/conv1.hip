@@ -184,10 +184,23 @@ void conv1_fprop(const bf16_raw* x, const bf16_raw* w1, const float* bias, bf16_
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4c1;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2c1;
 
+// FUSED: the layer is followed by BatchNorm + ReLU + 2x2 max-pool and `dy` is the gradient of
+// the POOLED output.  dL/d(conv output) is then produced on the fly, exactly as
+// bn_pool_bwd_apply_kernel would have stored it (same formula, same bf16 rounding, so the
+// result is bit-identical): a 128-pixel step is four image rows = 32 complete pooling windows,
+// thread = (window, 8 channels) re-derives the window's winner from the conv output `pre`
+// and writes the four pixels' gradients straight into the LDS tile.  The 33.5 MB gradient
+// tensor of the first layer (batch 256) is never written or read back.
+struct Conv1BnPool {
+    const uint16_t* pre;        // conv output [M][64]
+    const float *gamma, *beta, *mean, *rstd, *dgamma, *dbeta;
+};
+
+template <bool FUSED>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __restrict__ x,
                                                           const uint16_t* __restrict__ dy,
                                                           float* __restrict__ slab, int M,
-                                                          int steps_per_block) {
+                                                          int steps_per_block, Conv1BnPool bn) {
     constexpr int S = 192;
     constexpr int PX = 128;                      // pixels per step
     constexpr int kOOB = (int)0x80000000;
@@ -198,8 +211,29 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
     const int tco = wave & 1, tk = wave >> 1;
     const __amdgpu_buffer_rsrc_t xr =
         __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)M * 8u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dr =
-        __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (unsigned)M * 128u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)dy, 0, FUSED ? (unsigned)(M / 4) * 128u : (unsigned)M * 128u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(FUSED ? bn.pre : dy), 0, (unsigned)M * 128u, 0x00020000);
+    // FUSED: thread = (window widx of the step's 32, channel group cgr); per-channel constants
+    //   y = x*ysc + ysh (winner / live test),  dx = [winner] k1*g - k2 - k3*x
+    const int widx = tid >> 3, cgr = tid & 7;
+    float ysc[8], ysh[8], k1[8], k2[8], k3[8];
+    if (FUSED) {
+        const float inv_n = 1.f / (float)M;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int col = cgr * 8 + k;
+            const float rs = bn.rstd[col];
+            const float mrs = bn.mean[col] * rs;
+            ysc[k] = bn.gamma[col] * rs;
+            ysh[k] = __builtin_fmaf(-bn.gamma[col], mrs, bn.beta[col]);
+            k1[k] = bn.gamma[col] * rs;
+            const float dg = bn.dgamma[col] * inv_n, db = bn.dbeta[col] * inv_n;
+            k2[k] = k1[k] * __builtin_fmaf(-mrs, dg, db);
+            k3[k] = (k1[k] * rs) * dg;
+        }
+    }
 
     f32x16 acc;
 #pragma unroll
@@ -222,16 +256,30 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
 #pragma unroll
         for (int c = 5; c < 8; ++c) *(uint4*)(sC + crow * S + c * 16) = make_uint4(0, 0, 0, 0);
     }
-    u32x4c1 rd[4];
+    u32x4c1 rd[4], rg;
     u32x2c1 rt[5];
+    // local pixel rows of this thread's window: top-left, +1, +32, +33
+    const int wrow0 = (widx >> 4) * 64 + (widx & 15) * 2;
     auto load_step = [&](int s) {
         const int pbase = s * PX;
+        if (FUSED) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int chunk = tid + 256 * i;
-            const int pix = pbase + (chunk >> 3);
-            rd[i] = __builtin_amdgcn_raw_buffer_load_b128(
-                dr, pix < M ? pix * 128 + (chunk & 7) * 16 : kOOB, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                const int pix = pbase + wrow0 + (i >> 1) * 32 + (i & 1);
+                rd[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                    pr, pix < M ? pix * 128 + cgr * 16 : kOOB, 0, 0);
+            }
+            const int opix = s * 32 + widx;         // pooled pixel of this window
+            rg = __builtin_amdgcn_raw_buffer_load_b128(
+                dr, opix < M / 4 ? opix * 128 + cgr * 16 : kOOB, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int chunk = tid + 256 * i;
+                const int pix = pbase + (chunk >> 3);
+                rd[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                    dr, pix < M ? pix * 128 + (chunk & 7) * 16 : kOOB, 0, 0);
+            }
         }
         const int pix = pbase + crow;
         const int w_ = pix & 31, h_ = (pix >> 5) & 31;
@@ -247,10 +295,38 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
         if (chalf && pix < M) rt[4][0] = 0x3f80u;     // tap slot 9 = k 36: bf16 1.0 (bias column)
     };
     auto store_step = [&]() {
+        if (FUSED) {
+            float v[4][8], g[8], o[4][8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int chunk = tid + 256 * i;
-            *(u32x4c1*)(sD + (chunk >> 3) * S + (chunk & 7) * 16) = rd[i];
+            for (int i = 0; i < 4; ++i)
+                unpack8(make_uint4(rd[i][0], rd[i][1], rd[i][2], rd[i][3]), v[i]);
+            unpack8(make_uint4(rg[0], rg[1], rg[2], rg[3]), g);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // first maximum in row-major window order, strict comparisons, same fma as forward
+                int w = 0;
+                float m = __builtin_fmaf(v[0][k], ysc[k], ysh[k]);
+#pragma unroll
+                for (int i = 1; i < 4; ++i) {
+                    const float z = __builtin_fmaf(v[i][k], ysc[k], ysh[k]);
+                    if (z > m) { m = z; w = i; }
+                }
+                const float gk = m > 0.f ? k1[k] * g[k] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    o[i][k] = __builtin_fmaf(-k3[k], v[i][k], (w == i ? gk : 0.f) - k2[k]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 pk = pack8(o[i]);
+                *(uint4*)(sD + (wrow0 + (i >> 1) * 32 + (i & 1)) * S + cgr * 16) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int chunk = tid + 256 * i;
+                *(u32x4c1*)(sD + (chunk >> 3) * S + (chunk & 7) * 16) = rd[i];
+            }
         }
         // half 0: k 0..19 (taps 0..4), half 1: k 20..39 (taps 5..8 + bias column): 40 bytes each
         char* dst = sC + crow * S + chalf * 40;
@@ -355,9 +431,27 @@ void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, in
     const int M = batch * 1024;
     int spb;
     const int blocks = conv1_wgrad_blocks(M, &spb);
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, x, dy, ws, M, spb);
+    hipLaunchKernelGGL(conv1_wgrad_kernel<false>, dim3(blocks), dim3(256), 0, stream, x, dy, ws, M,
+                       spb, Conv1BnPool{});
     hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(160), dim3(256), 0, stream,
                        (const float*)ws, dw, db, blocks);
+}
+
+void conv1_wgrad_bn_pool(const bf16_raw* x, const bf16_raw* pre, const bf16_raw* dy_pooled,
+                         const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_rstd, const float* dgamma, const float* dbeta, float* dw,
+                         int batch, float* ws, hipStream_t stream) {
+    if (batch <= 0) return;
+    if ((long long)batch * 1024 * 128 >= (1LL << 31))
+        throw std::invalid_argument("conv1_wgrad_bn_pool: batch too large");
+    const int M = batch * 1024;
+    int spb;
+    const int blocks = conv1_wgrad_blocks(M, &spb);
+    const Conv1BnPool bn = {pre, gamma, beta, save_mean, save_rstd, dgamma, dbeta};
+    hipLaunchKernelGGL(conv1_wgrad_kernel<true>, dim3(blocks), dim3(256), 0, stream, x, dy_pooled,
+                       ws, M, spb, bn);
+    hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(160), dim3(256), 0, stream,
+                       (const float*)ws, dw, (float*)nullptr, blocks);
 }
 
 }  // namespace dml

@@ -176,6 +176,34 @@ def conv1_wgrad(x4: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Tensor, torch
     return dw, db
 
 
+def conv1_wgrad_bn_pool(x4, pre, dy_pooled, gamma, beta, save_mean, save_rstd):
+    """Weight gradient of a first layer followed by BatchNorm + ReLU + 2x2 max-pool, from the
+    gradient of the pooled output; the full-resolution gradient is never materialised.
+    Returns ``(dw, dgamma, dbeta)``."""
+    _req(x4, torch.bfloat16, "x4", 4)
+    _req(pre, torch.bfloat16, "pre", 4)
+    _req(dy_pooled, torch.bfloat16, "dy_pooled", 4)
+    b = x4.shape[0]
+    if tuple(x4.shape[1:]) != (32, 32, 4) or tuple(pre.shape) != (b, 32, 32, 64) or \
+            tuple(dy_pooled.shape) != (b, 16, 16, 64):
+        raise ValueError("conv1_wgrad_bn_pool: shape mismatch")
+    dev = x4.device
+    dgamma = torch.empty(64, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(64, dtype=torch.float32, device=dev)
+    # reductions only (dx == nullptr): dgamma / dbeta
+    lib().bn_relu_pool_bwd(pre.data_ptr(), dy_pooled.data_ptr(), 0, gamma.data_ptr(),
+                           beta.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
+                           dgamma.data_ptr(), dbeta.data_ptr(), _reduce_ws(dev).data_ptr(),
+                           b, 32, 64, _stream())
+    dw = torch.zeros(64, 3, 3, 3, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib().conv1_wgrad_workspace_elems(b), dtype=torch.float32, device=dev)
+    lib().conv1_wgrad_bn_pool(x4.data_ptr(), pre.data_ptr(), dy_pooled.data_ptr(), gamma.data_ptr(),
+                              beta.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
+                              dgamma.data_ptr(), dbeta.data_ptr(), dw.data_ptr(), b, ws.data_ptr(),
+                              _stream())
+    return dw, dgamma, dbeta
+
+
 def column_sum(x: torch.Tensor) -> torch.Tensor:
     """Sum over all leading dims of a bf16 tensor whose last dim is the channel."""
     _req(x, torch.bfloat16, "x")

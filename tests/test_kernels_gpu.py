@@ -340,6 +340,41 @@ def test_bn_relu_pool_fused(c, shape):
     check("bn+pool eval", nchw(ye), refe)
 
 
+@pytest.mark.parametrize("batch", [2, 64])
+def test_conv1_wgrad_with_bn_pool_backward_on_the_fly(batch):
+    """First layer under BatchNorm + ReLU + max-pool: the weight-gradient kernel that forms
+    dL/d(conv output) on the fly must give what the stored-gradient path gives (same formula,
+    same bf16 rounding of the gradient), and match torch autograd through conv -> BN -> ReLU
+    -> pool."""
+    n = native()
+    torch.manual_seed(5)
+    x = rand_bf16(batch, 32, 32, 3, seed=41)
+    x4 = torch.zeros(batch, 32, 32, 4, dtype=torch.bfloat16, device=DEV)
+    x4[..., :3] = x
+    w = (torch.randn(64, 3, 3, 3, device=DEV) * 0.2)        # [cout][kh][kw][cin]
+    bias = torch.randn(64, device=DEV) * 0.1
+    gamma = torch.rand(64, device=DEV) + 0.5
+    beta = torch.randn(64, device=DEV) * 0.2
+    pre = n.conv1_fwd(x4, n.pack_conv1_weights(w), bias, relu=False)
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    y, mean, rstd = n.bn_relu_pool_fwd_train(pre, gamma, beta, rm, rv)
+    dy = rand_bf16(batch, 16, 16, 64, seed=42)
+    g, dgamma_a, dbeta_a = n.bn_relu_pool_bwd(pre, dy, gamma, beta, mean, rstd)
+    dw_a, _ = n.conv1_wgrad(x4, g)
+    dw_b, dgamma_b, dbeta_b = n.conv1_wgrad_bn_pool(x4, pre, dy, gamma, beta, mean, rstd)
+    assert torch.equal(dgamma_a, dgamma_b) and torch.equal(dbeta_a, dbeta_b)
+    check("conv1 wgrad fused vs stored gradient", dw_b, dw_a, rtol=1e-4, atol_scale=1e-4)
+    # against autograd on the bf16-rounded operands
+    wr = w.to(torch.bfloat16).float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    conv = F.conv2d(nchw(x).float(), wr, bias, padding=1)
+    # forward values = the bf16 conv output the kernels saw (pooling winners and ReLU signs
+    # flip on rounding), gradient path = the fp32 convolution
+    conv = conv + (nchw(pre).float() - conv).detach()
+    ref = F.max_pool2d(F.relu(F.batch_norm(conv, None, None, gamma, beta, True, 0.1, 1e-5)), 2)
+    ref.backward(nchw(dy).float())
+    check("conv1 wgrad fused vs torch", dw_b, wr.grad.permute(0, 2, 3, 1), rtol=3e-2, atol_scale=3e-2)
+
+
 @pytest.mark.parametrize("batch", [3, 256])
 def test_linear_and_softmax_xent(batch):
     n = native()
