@@ -92,6 +92,12 @@ PYBIND11_MODULE(_C, m) {
                     batch, ptr<float>(ws), st(stream));
     });
     m.def("conv1_wgrad_workspace_elems", &conv1_wgrad_workspace_elems);
+    m.def("conv1_wgrad_relu_pool", [](uintptr_t x, uintptr_t act, uintptr_t dyp, uintptr_t dw,
+                                      uintptr_t db, int batch, uintptr_t ws, uintptr_t s) {
+        conv1_wgrad_relu_pool(ptr<const bf16_raw>(x), ptr<const bf16_raw>(act),
+                              ptr<const bf16_raw>(dyp), ptr<float>(dw), ptr<float>(db), batch,
+                              ptr<float>(ws), st(s));
+    });
     m.def("conv1_wgrad_bn_pool", [](uintptr_t x, uintptr_t pre, uintptr_t dyp, uintptr_t gamma,
                                     uintptr_t beta, uintptr_t mean, uintptr_t rstd, uintptr_t dgamma,
                                     uintptr_t dbeta, uintptr_t dw, int batch, uintptr_t ws,

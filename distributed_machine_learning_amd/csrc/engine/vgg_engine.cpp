@@ -458,21 +458,24 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
         const int rows = batch * c.hw * c.hw;
         uint16_t* g = arena_ + c.gout_off;       // dL/d(conv output), ReLU mask applied
         // first layer under BatchNorm + pool: its weight-gradient kernel forms g on the fly
-        const bool g_on_the_fly = i == 0 && bn_ && c.pool_after;
+        const bool g_on_the_fly = i == 0 && c.pool_after;
         if (bn_ && c.pool_after)
             bn_relu_pool_bwd(arena_ + c.pre_off, transit, g_on_the_fly ? nullptr : g,
                              params_ + c.gamma_off,
                              params_ + c.beta_off, ws_ + c.save_off, ws_ + c.save_off + c.cout,
                              grads_ + c.gamma_off, grads_ + c.beta_off, ws_ + stats_off_, batch,
                              c.hw, c.cout, stream);
-        else if (c.pool_after)
+        else if (c.pool_after && !g_on_the_fly)
             maxpool2x2_bwd(arena_ + c.out_off, transit, g, batch, c.hw, c.cout, /*relu_mask=*/true,
                            stream);
         else if (bn_)
             bn_relu_bwd(arena_ + c.pre_off, transit, g, params_ + c.gamma_off, params_ + c.beta_off,
                         ws_ + c.save_off, ws_ + c.save_off + c.cout, grads_ + c.gamma_off,
                         grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream);
-        if (g_on_the_fly) {
+        if (g_on_the_fly && !bn_) {
+            conv1_wgrad_relu_pool(x, arena_ + c.out_off, transit, grads_ + c.w_off,
+                                  grads_ + c.b_off, batch, slab, stream);
+        } else if (g_on_the_fly) {
             conv1_wgrad_bn_pool(x, arena_ + c.pre_off, transit, params_ + c.gamma_off,
                                 params_ + c.beta_off, ws_ + c.save_off, ws_ + c.save_off + c.cout,
                                 grads_ + c.gamma_off, grads_ + c.beta_off, grads_ + c.w_off, batch,

@@ -78,6 +78,9 @@ void conv1_wgrad_bn_pool(const bf16_raw* x, const bf16_raw* pre, const bf16_raw*
                          const float* gamma, const float* beta, const float* save_mean,
                          const float* save_rstd, const float* dgamma, const float* dbeta, float* dw,
                          int batch, float* ws, hipStream_t stream);
+// First layer followed by ReLU + 2x2 max-pool (no BatchNorm): `act` is the stored ReLU output.
+void conv1_wgrad_relu_pool(const bf16_raw* x, const bf16_raw* act, const bf16_raw* dy_pooled,
+                           float* dw, float* db, int batch, float* ws, hipStream_t stream);
 
 // dw[cout][9][cin] (+)= sum_p dy[p][cout] * x[p (+) tap][cin]   (fp32).  The pixel range is
 // split over several blocks per tile.  Without `slab` the splits accumulate into `dw` with

@@ -196,11 +196,15 @@ struct Conv1BnPool {
     const float *gamma, *beta, *mean, *rstd, *dgamma, *dbeta;
 };
 
-template <bool FUSED>
+// MODE 0: dy is dL/d(conv output).  MODE 1: BatchNorm + ReLU + pool follow (see above).
+// MODE 2: ReLU + pool follow, `bn.pre` is the stored ReLU output: the pooled gradient goes to
+// the window's first maximum if that is positive (what maxpool2x2_bwd with relu_mask stores).
+template <int MODE>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __restrict__ x,
                                                           const uint16_t* __restrict__ dy,
                                                           float* __restrict__ slab, int M,
                                                           int steps_per_block, Conv1BnPool bn) {
+    constexpr bool FUSED = MODE != 0;
     constexpr int S = 192;
     constexpr int PX = 128;                      // pixels per step
     constexpr int kOOB = (int)0x80000000;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
     //   y = x*ysc + ysh (winner / live test),  dx = [winner] k1*g - k2 - k3*x
     const int widx = tid >> 3, cgr = tid & 7;
     float ysc[8], ysh[8], k1[8], k2[8], k3[8];
-    if (FUSED) {
+    if (MODE == 1) {
         const float inv_n = 1.f / (float)M;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -301,6 +305,19 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
             for (int i = 0; i < 4; ++i)
                 unpack8(make_uint4(rd[i][0], rd[i][1], rd[i][2], rd[i][3]), v[i]);
             unpack8(make_uint4(rg[0], rg[1], rg[2], rg[3]), g);
+            if (MODE == 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int w = 0;
+                    float m = v[0][k];
+#pragma unroll
+                    for (int i = 1; i < 4; ++i)
+                        if (v[i][k] > m) { m = v[i][k]; w = i; }
+                    const float gk = m > 0.f ? g[k] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i][k] = w == i ? gk : 0.f;
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 // first maximum in row-major window order, strict comparisons, same fma as forward
@@ -315,6 +332,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     o[i][k] = __builtin_fmaf(-k3[k], v[i][k], (w == i ? gk : 0.f) - k2[k]);
+            }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -431,7 +449,7 @@ void conv1_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, float* db, in
     const int M = batch * 1024;
     int spb;
     const int blocks = conv1_wgrad_blocks(M, &spb);
-    hipLaunchKernelGGL(conv1_wgrad_kernel<false>, dim3(blocks), dim3(256), 0, stream, x, dy, ws, M,
+    hipLaunchKernelGGL(conv1_wgrad_kernel<0>, dim3(blocks), dim3(256), 0, stream, x, dy, ws, M,
                        spb, Conv1BnPool{});
     hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(160), dim3(256), 0, stream,
                        (const float*)ws, dw, db, blocks);
@@ -448,10 +466,26 @@ void conv1_wgrad_bn_pool(const bf16_raw* x, const bf16_raw* pre, const bf16_raw*
     int spb;
     const int blocks = conv1_wgrad_blocks(M, &spb);
     const Conv1BnPool bn = {pre, gamma, beta, save_mean, save_rstd, dgamma, dbeta};
-    hipLaunchKernelGGL(conv1_wgrad_kernel<true>, dim3(blocks), dim3(256), 0, stream, x, dy_pooled,
+    hipLaunchKernelGGL(conv1_wgrad_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, dy_pooled,
                        ws, M, spb, bn);
     hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(160), dim3(256), 0, stream,
                        (const float*)ws, dw, (float*)nullptr, blocks);
+}
+
+void conv1_wgrad_relu_pool(const bf16_raw* x, const bf16_raw* act, const bf16_raw* dy_pooled,
+                           float* dw, float* db, int batch, float* ws, hipStream_t stream) {
+    if (batch <= 0) return;
+    if ((long long)batch * 1024 * 128 >= (1LL << 31))
+        throw std::invalid_argument("conv1_wgrad_relu_pool: batch too large");
+    const int M = batch * 1024;
+    int spb;
+    const int blocks = conv1_wgrad_blocks(M, &spb);
+    Conv1BnPool a = {};
+    a.pre = act;
+    hipLaunchKernelGGL(conv1_wgrad_kernel<2>, dim3(blocks), dim3(256), 0, stream, x, dy_pooled, ws,
+                       M, spb, a);
+    hipLaunchKernelGGL(conv1_wgrad_finish_kernel, dim3(160), dim3(256), 0, stream,
+                       (const float*)ws, dw, db, blocks);
 }
 
 }  // namespace dml

@@ -176,6 +176,24 @@ def conv1_wgrad(x4: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Tensor, torch
     return dw, db
 
 
+def conv1_wgrad_relu_pool(x4, act, dy_pooled):
+    """Weight / bias gradient of a first layer followed by ReLU + 2x2 max-pool, from the stored
+    ReLU output and the gradient of the pooled output.  Returns ``(dw, db)``."""
+    _req(x4, torch.bfloat16, "x4", 4)
+    _req(act, torch.bfloat16, "act", 4)
+    _req(dy_pooled, torch.bfloat16, "dy_pooled", 4)
+    b = x4.shape[0]
+    if tuple(x4.shape[1:]) != (32, 32, 4) or tuple(act.shape) != (b, 32, 32, 64) or \
+            tuple(dy_pooled.shape) != (b, 16, 16, 64):
+        raise ValueError("conv1_wgrad_relu_pool: shape mismatch")
+    dw = torch.zeros(64, 3, 3, 3, dtype=torch.float32, device=x4.device)
+    db = torch.zeros(64, dtype=torch.float32, device=x4.device)
+    ws = torch.empty(lib().conv1_wgrad_workspace_elems(b), dtype=torch.float32, device=x4.device)
+    lib().conv1_wgrad_relu_pool(x4.data_ptr(), act.data_ptr(), dy_pooled.data_ptr(), dw.data_ptr(),
+                                db.data_ptr(), b, ws.data_ptr(), _stream())
+    return dw, db
+
+
 def conv1_wgrad_bn_pool(x4, pre, dy_pooled, gamma, beta, save_mean, save_rstd):
     """Weight gradient of a first layer followed by BatchNorm + ReLU + 2x2 max-pool, from the
     gradient of the pooled output; the full-resolution gradient is never materialised.

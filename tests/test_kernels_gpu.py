@@ -375,6 +375,25 @@ def test_conv1_wgrad_with_bn_pool_backward_on_the_fly(batch):
     check("conv1 wgrad fused vs torch", dw_b, wr.grad.permute(0, 2, 3, 1), rtol=3e-2, atol_scale=3e-2)
 
 
+@pytest.mark.parametrize("batch", [2, 64])
+def test_conv1_wgrad_with_relu_pool_backward_on_the_fly(batch):
+    """First layer followed by ReLU + max-pool: forming the routed gradient inside the
+    weight-gradient kernel equals storing it with maxpool2x2_bwd first (exactly: the routed
+    values are copies of the incoming gradient)."""
+    n = native()
+    x = rand_bf16(batch, 32, 32, 3, seed=43)
+    x4 = torch.zeros(batch, 32, 32, 4, dtype=torch.bfloat16, device=DEV)
+    x4[..., :3] = x
+    w = torch.randn(64, 3, 3, 3, device=DEV) * 0.2
+    bias = torch.randn(64, device=DEV) * 0.1
+    act = n.conv1_fwd(x4, n.pack_conv1_weights(w), bias, relu=True)
+    dy = rand_bf16(batch, 16, 16, 64, seed=44)
+    g = n.maxpool2x2_bwd(act, dy, relu_mask=True)
+    dw_a, db_a = n.conv1_wgrad(x4, g)
+    dw_b, db_b = n.conv1_wgrad_relu_pool(x4, act, dy)
+    assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b)
+
+
 @pytest.mark.parametrize("batch", [3, 256])
 def test_linear_and_softmax_xent(batch):
     n = native()
