@@ -498,8 +498,9 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             if (bucket_leaves(i)) owed.push_back(i);
             const bool full = (int)wgrad_queue_.size() >= wgrad_group_ ||
                               (i <= 1 && !wgrad_queue_.empty());
-            // (without a reducer the last layer's few parameters finish on the main stream)
-            hand = full || bucket_leaves(i) || (i == 0 && !owed.empty());
+            // (layer 0 finishes on the main stream: its weight gradient runs there, and a last
+            // bucket that leaves from the main stream saves a cross-queue hop on the critical path)
+            hand = i > 0 && (full || bucket_leaves(i));
             if (hand) check_hip(hipEventRecord(hand_off_[i], stream), "hipEventRecord(hand-off)");
         }
         if (i > 0) {
@@ -522,18 +523,22 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                 sgd_slice(layer_begin(i), layer_begin(updated_above), wgrad_stream_);
                 updated_above = i;
             }
-            if (!reducer_ && i <= 1) {      // the side stream's last work of this step
+            if (i <= 1) {                   // the side stream's last work of this step
                 check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
                 side_done_recorded_ = true;
             }
         }
+        if (side && i == 0 && !owed.empty()) {
+            join_wgrad_stream(stream);      // usually fired long ago (recorded at the last hand-off)
+            for (int l : owed)
+                for (int b : buckets_by_layer_[l])
+                    reducer_->bucket_ready(b, stream, bucket_update(b));
+            owed.clear();
+        }
         if (!side) fire_buckets(i, stream);
     }
     if (side) {
-        // with a reducer the last bucket left from the side stream after all of its work, and
-        // the optimizer waits for that bucket; otherwise the main stream waits here (this also
-        // rejoins the side stream into a graph capture)
-        if (reducer_ && bucket_leaves(0)) side_busy_ = false;
+        // the main stream waits for the side stream (this also rejoins it into a graph capture)
         join_wgrad_stream(stream);
         if (fuse_opt && !reducer_) sgd_slice(0, layer_begin(updated_above), stream);
     } else {
