@@ -82,6 +82,11 @@ def parse():
 
 def main():
     ns = parse()
+    # stdout carries exactly one line, the JSON record; everything else a library prints there
+    # (RCCL's version banner at its first collective) is sent to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -181,7 +186,7 @@ def main():
         ms = elapsed / ns.steps * 1e3
         value = ns.batch_size * world * ns.steps / elapsed
         par = "single" if world == 1 else f"dp{world}"
-        print(json.dumps({
+        record = json.dumps({
             "metric": "images/sec, VGG-11 CIFAR-10-shaped training, batch 256 per GPU",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": ns.steps,
             "warmup": ns.warmup, "ms_per_step": round(ms, 4), "s_per_iter": round(ms / 1e3, 7),
@@ -196,7 +201,8 @@ def main():
                        "host_enqueue_ms_per_step": round(host_elapsed / probe * 1e3, 4),
                        "final_loss": round(final_loss, 4), "overlap": overlap,
                        "baseline": "reference part3: 305.4 images/s on 4 CPU nodes "
-                                   "(group25.pdf p7); part1: 106.8 images/s"}}))
+                                   "(group25.pdf p7); part1: 106.8 images/s"}})
+        print(record, file=json_out, flush=True)
     backend.close()
     if comm is not None:
         comm.destroy()
