@@ -268,7 +268,7 @@ void VggEngine::launch_wgrad(int i, int batch, hipStream_t stream) {
 // (the queued layers' gradients, the BatchNorm / classifier gradients of a departing bucket)
 // becomes visible to the side stream, which then runs the queued weight gradients and their sums.
 void VggEngine::hand_off_wgrads(int layer, int batch) {
-    check_hip(hipStreamWaitEvent(wgrad_stream_, hand_off_[layer], 0), "hipStreamWaitEvent(hand-off)");
+    (void)layer;        // the caller has ordered the side stream behind hand_off_[layer]
     for (int i : wgrad_queue_) launch_wgrad(i, batch, wgrad_stream_);
     wgrad_queue_.clear();
     flush_wgrad_sums(wgrad_stream_);
@@ -445,10 +445,17 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     auto arriving = [&](int i) { return staged(i) ? transit : arena_ + convs_[i].gout_off; };
     auto bucket_leaves = [&](int layer) { return reducer_ && !buckets_by_layer_[layer].empty(); };
 
-    // classifier + loss, forward and backward, in two launches; every output is overwritten
-    fc_train(fc_in, params_ + fcw_off_, params_ + fcb_off_, target, ws_ + logits_off_,
-             ws_ + loss_off_, nullptr, arriving(nconv - 1), grads_ + fcw_off_, grads_ + fcb_off_,
-             ws_ + fc_ws_off_, batch, fc_in_, num_classes_, stream);
+    // classifier + loss, forward and backward, in two launches; every output is overwritten.
+    // Only the per-row half (dlogits, dx) is on the way to the conv layers; the batch reductions
+    // (dW, db, loss) go to the side stream with the first hand-off when there is one.
+    fc_train_rows(fc_in, params_ + fcw_off_, params_ + fcb_off_, target, ws_ + logits_off_,
+                  arriving(nconv - 1), ws_ + fc_ws_off_, batch, fc_in_, num_classes_, stream);
+    auto fc_grads = [this, fc_in, batch](hipStream_t s) {
+        fc_train_grads(fc_in, ws_ + fc_ws_off_, ws_ + loss_off_, nullptr, grads_ + fcw_off_,
+                       grads_ + fcb_off_, batch, fc_in_, num_classes_, s);
+    };
+    bool fc_grads_pending = side;
+    if (!side) fc_grads(stream);
     // side mode: a completed bucket leaves (from the side stream) with the next hand-off
     std::vector<int> owed;          // layers whose buckets are complete but not yet sent off
     if (!side) fire_buckets(nconv, stream);
@@ -513,6 +520,11 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                           fold_relu ? EPI_MASK : EPI_NONE, stream);
         }
         if (hand) {
+            check_hip(hipStreamWaitEvent(wgrad_stream_, hand_off_[i], 0), "hipStreamWaitEvent(hand-off)");
+            if (fc_grads_pending) {
+                fc_grads(wgrad_stream_);
+                fc_grads_pending = false;
+            }
             hand_off_wgrads(i, batch);
             for (int l : owed)
                 for (int b : buckets_by_layer_[l])
@@ -527,6 +539,10 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                 check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
                 side_done_recorded_ = true;
             }
+        }
+        if (i == 0 && fc_grads_pending) {    // a network with a single conv layer: no hand-off
+            fc_grads(stream);
+            fc_grads_pending = false;
         }
         if (side && i == 0 && !owed.empty()) {
             join_wgrad_stream(stream);      // usually fired long ago (recorded at the last hand-off)

@@ -187,6 +187,14 @@ void fc_train(const bf16_raw* x, const float* w, const float* bias, const int64_
               float* logits, float* loss, int32_t* correct, bf16_raw* dx, float* dw, float* db,
               float* ws, int batch, int in_features, int out_features, hipStream_t stream);
 size_t fc_train_workspace_elems(int batch, int in_features, int out_features);
+// The two halves of fc_train: everything that needs only its own batch row (logits, dlogits
+// and per-row loss terms into `ws`, dx), and the reductions over the batch (dW, db, loss,
+// accuracy), which nothing in the rest of backward waits for.
+void fc_train_rows(const bf16_raw* x, const float* w, const float* bias, const int64_t* target,
+                   float* logits, bf16_raw* dx, float* ws, int batch, int in_features,
+                   int out_features, hipStream_t stream);
+void fc_train_grads(const bf16_raw* x, const float* ws, float* loss, int32_t* correct, float* dw,
+                    float* db, int batch, int in_features, int out_features, hipStream_t stream);
 
 // ---------------------------------------------------------------- optimiser
 // g' = g * grad_scale + wd * p;  m = first ? g' : mu * m + g';  p -= lr * m.

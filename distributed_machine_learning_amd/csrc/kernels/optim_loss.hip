@@ -434,22 +434,43 @@ size_t fc_train_workspace_elems(int batch, int in_features, int out_features) {
     return (size_t)batch * (kFcMaxClasses + 2);      // dlogits [batch][16] + (loss term, hit) per row
 }
 
-void fc_train(const bf16_raw* x, const float* w, const float* bias, const int64_t* target,
-              float* logits, float* loss, int32_t* correct, bf16_raw* dx, float* dw, float* db,
-              float* ws, int batch, int in_features, int out_features, hipStream_t stream) {
+namespace {
+void fc_check(int batch, int in_features, int out_features) {
     if (in_features != 512)
         throw std::invalid_argument("fc_train: the fused classifier step handles 512 input features");
     if (out_features < 1 || out_features > kFcMaxClasses)
         throw std::invalid_argument("fc_train: 1..16 classes");
+    (void)batch;
+}
+}  // namespace
+
+void fc_train_rows(const bf16_raw* x, const float* w, const float* bias, const int64_t* target,
+                   float* logits, bf16_raw* dx, float* ws, int batch, int in_features,
+                   int out_features, hipStream_t stream) {
+    fc_check(batch, in_features, out_features);
     if (batch <= 0) return;
     float* dlogits = ws;
     float* rowstat = ws + (size_t)batch * kFcMaxClasses;
     hipLaunchKernelGGL(fc_train_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, x, w, bias,
                        target, logits, dx, dlogits, rowstat, batch, in_features, out_features,
                        1.0f / (float)batch);
+}
+
+void fc_train_grads(const bf16_raw* x, const float* ws, float* loss, int32_t* correct, float* dw,
+                    float* db, int batch, int in_features, int out_features, hipStream_t stream) {
+    fc_check(batch, in_features, out_features);
+    if (batch <= 0) return;
+    const float* dlogits = ws;
+    const float* rowstat = ws + (size_t)batch * kFcMaxClasses;
     hipLaunchKernelGGL(fc_train_grads_kernel, dim3(in_features / kFcCols), dim3(256), 0, stream, x,
-                       (const float*)dlogits, (const float*)rowstat, dw, db, loss, correct, batch,
-                       in_features, out_features);
+                       dlogits, rowstat, dw, db, loss, correct, batch, in_features, out_features);
+}
+
+void fc_train(const bf16_raw* x, const float* w, const float* bias, const int64_t* target,
+              float* logits, float* loss, int32_t* correct, bf16_raw* dx, float* dw, float* db,
+              float* ws, int batch, int in_features, int out_features, hipStream_t stream) {
+    fc_train_rows(x, w, bias, target, logits, dx, ws, batch, in_features, out_features, stream);
+    fc_train_grads(x, ws, loss, correct, dw, db, batch, in_features, out_features, stream);
 }
 
 }  // namespace dml
