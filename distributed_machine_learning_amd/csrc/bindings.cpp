@@ -144,12 +144,16 @@ PYBIND11_MODULE(_C, m) {
     });
     m.def("bn_relu_bwd", [](uintptr_t x, uintptr_t dy, uintptr_t dx, uintptr_t gamma,
                             uintptr_t beta, uintptr_t smean, uintptr_t srstd, uintptr_t dgamma,
-                            uintptr_t dbeta, uintptr_t ws, int rows, int c, uintptr_t s) {
-        bn_relu_bwd(ptr<const bf16_raw>(x), ptr<const bf16_raw>(dy), ptr<bf16_raw>(dx),
+                            uintptr_t dbeta, uintptr_t ws, int rows, int c, uintptr_t s,
+                            uintptr_t slabs, int splits, size_t stride) {
+        bn_relu_bwd(ptr<const bf16_raw>(x), ptr<bf16_raw>(dy), ptr<bf16_raw>(dx),
                     ptr<const float>(gamma), ptr<const float>(beta), ptr<const float>(smean),
                     ptr<const float>(srstd), ptr<float>(dgamma), ptr<float>(dbeta), ptr<float>(ws),
-                    rows, c, st(s));
-    });
+                    rows, c, st(s), SplitSlabs{ptr<const float>(slabs), splits, stride});
+    }, py::arg("x"), py::arg("dy"), py::arg("dx"), py::arg("gamma"), py::arg("beta"),
+       py::arg("save_mean"), py::arg("save_rstd"), py::arg("dgamma"), py::arg("dbeta"),
+       py::arg("ws"), py::arg("rows"), py::arg("c"), py::arg("stream"), py::arg("slabs") = 0,
+       py::arg("splits") = 0, py::arg("stride") = 0);
     m.def("bn_relu_pool_fwd_train", [](uintptr_t x, uintptr_t y, uintptr_t gamma, uintptr_t beta,
                                        uintptr_t rmean, uintptr_t rvar, uintptr_t smean,
                                        uintptr_t srstd, uintptr_t ws, int batch, int hw, int c,
@@ -169,12 +173,16 @@ PYBIND11_MODULE(_C, m) {
     m.def("bn_relu_pool_bwd", [](uintptr_t x, uintptr_t dy, uintptr_t dx, uintptr_t gamma,
                                  uintptr_t beta, uintptr_t smean, uintptr_t srstd, uintptr_t dgamma,
                                  uintptr_t dbeta, uintptr_t ws, int batch, int hw, int c,
-                                 uintptr_t s) {
-        bn_relu_pool_bwd(ptr<const bf16_raw>(x), ptr<const bf16_raw>(dy), ptr<bf16_raw>(dx),
+                                 uintptr_t s, uintptr_t slabs, int splits, size_t stride) {
+        bn_relu_pool_bwd(ptr<const bf16_raw>(x), ptr<bf16_raw>(dy), ptr<bf16_raw>(dx),
                          ptr<const float>(gamma), ptr<const float>(beta), ptr<const float>(smean),
                          ptr<const float>(srstd), ptr<float>(dgamma), ptr<float>(dbeta),
-                         ptr<float>(ws), batch, hw, c, st(s));
-    });
+                         ptr<float>(ws), batch, hw, c, st(s),
+                         SplitSlabs{ptr<const float>(slabs), splits, stride});
+    }, py::arg("x"), py::arg("dy"), py::arg("dx"), py::arg("gamma"), py::arg("beta"),
+       py::arg("save_mean"), py::arg("save_rstd"), py::arg("dgamma"), py::arg("dbeta"),
+       py::arg("ws"), py::arg("batch"), py::arg("hw"), py::arg("c"), py::arg("stream"),
+       py::arg("slabs") = 0, py::arg("splits") = 0, py::arg("stride") = 0);
     m.def("streams_run_concurrently", [](uintptr_t busy, uintptr_t candidate) {
         return streams_run_concurrently((hipStream_t)busy, (hipStream_t)candidate);
     });

@@ -460,6 +460,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     std::vector<int> owed;          // layers whose buckets are complete but not yet sent off
     if (!side) fire_buckets(nconv, stream);
     else if (bucket_leaves(nconv)) owed.push_back(nconv);
+    SplitSlabs pending;     // the arriving gradient is still a split convolution's unsummed slabs
     for (int i = nconv - 1; i >= 0; --i) {
         const Conv& c = convs_[i];
         const int rows = batch * c.hw * c.hw;
@@ -471,14 +472,14 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                              params_ + c.gamma_off,
                              params_ + c.beta_off, ws_ + c.save_off, ws_ + c.save_off + c.cout,
                              grads_ + c.gamma_off, grads_ + c.beta_off, ws_ + stats_off_, batch,
-                             c.hw, c.cout, stream);
+                             c.hw, c.cout, stream, pending);
         else if (c.pool_after && !g_on_the_fly)
             maxpool2x2_bwd(arena_ + c.out_off, transit, g, batch, c.hw, c.cout, /*relu_mask=*/true,
                            stream);
         else if (bn_)
             bn_relu_bwd(arena_ + c.pre_off, transit, g, params_ + c.gamma_off, params_ + c.beta_off,
                         ws_ + c.save_off, ws_ + c.save_off + c.cout, grads_ + c.gamma_off,
-                        grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream);
+                        grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream, pending);
         if (g_on_the_fly && !bn_) {
             conv1_wgrad_relu_pool(x, arena_ + c.out_off, transit, grads_ + c.w_off,
                                   grads_ + c.b_off, batch, slab, stream);
@@ -515,9 +516,12 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             const Conv& prev = convs_[i - 1];
             ConvShape d = {batch, c.hw, c.cout, c.cin};
             const bool fold_relu = !staged(i - 1);
+            // under BatchNorm the consumer is a reduction pass that can sum split slabs itself
+            pending = SplitSlabs{};
             conv3x3_igemm(g, arena_ + c.wd_off, arriving(i - 1), nullptr,
                           fold_relu ? arena_ + prev.out_off : nullptr, slab, slab_elems_, d,
-                          fold_relu ? EPI_MASK : EPI_NONE, stream);
+                          fold_relu ? EPI_MASK : EPI_NONE, stream, nullptr, nullptr,
+                          bn_ ? &pending : nullptr);
         }
         if (hand) {
             check_hip(hipStreamWaitEvent(wgrad_stream_, hand_off_[i], 0), "hipStreamWaitEvent(hand-off)");

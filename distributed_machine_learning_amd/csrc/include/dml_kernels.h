@@ -41,11 +41,21 @@ struct ConvShape {
 // w = repacked weights [cin][9 flipped][cout] (see repack_dgrad_weights), roles of
 // cin/cout swapped by the caller.  `workspace` (fp32, >= splits*M*N elements) is used
 // when the launcher decides to split the reduction over taps.
+// Partial results of a convolution that split its reduction: `splits` fp32 slabs of the
+// output, `stride` elements apart, still to be summed (splits == 0: nothing pending).
+struct SplitSlabs {
+    const float* data = nullptr;
+    int splits = 0;
+    size_t stride = 0;
+};
+// `defer` (EPI_NONE only): when the launcher splits the reduction, leave the sum of the slabs to
+// the consumer (a BatchNorm backward reduction reads the result anyway) and describe them in
+// *defer instead of launching the finishing kernel; y is then NOT written.
 void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
                    const bf16_raw* mask, float* workspace, size_t workspace_elems,
                    ConvShape s, ConvEpilogue epi, hipStream_t stream,
                    const int* force_plan = nullptr /* tuning: {BM, BN, splits, position-major (-1 auto), waves} */,
-                   float* stats = nullptr);
+                   float* stats = nullptr, SplitSlabs* defer = nullptr);
 size_t conv3x3_igemm_workspace_elems(ConvShape s);
 // With `stats` (EPI_BIAS, default plan) the kernel also leaves per-tile column sums and sums
 // of squares of the BIAS-FREE output: stats[row][0][n], stats[row][1][n] for
@@ -146,10 +156,14 @@ void bn_relu_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const 
 // dx, dgamma, dbeta from dy (grad of the ReLU output), the saved input x and statistics.
 // `stats_ws` as above; dgamma/dbeta are overwritten.
 size_t bn_workspace_elems();
-void bn_relu_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+// With `dy_slabs` (splits > 0) the incoming gradient is still the unsummed partial results of
+// the convolution that produced it: the reduction pass sums them, WRITES the bf16 result to
+// dy (the apply pass reads it) and works on the rounded values, i.e. exactly what a separate
+// finishing kernel followed by this call would compute.
+void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
                  const float* beta, const float* save_mean, const float* save_rstd,
                  float* dgamma, float* dbeta, float* stats_ws, int rows, int c,
-                 hipStream_t stream);
+                 hipStream_t stream, SplitSlabs dy_slabs = {});
 
 // BatchNorm + ReLU + 2x2/2 max-pool in one pass each way (x is the conv output
 // [batch][hw][hw][c], y / dy the pooled tensor [batch][hw/2][hw/2][c]).  The full-resolution
@@ -162,10 +176,10 @@ void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, 
 void bn_relu_pool_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                            const float* running_mean, const float* running_var, int batch, int hw,
                            int c, float eps, hipStream_t stream);
-void bn_relu_pool_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+void bn_relu_pool_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
                       const float* beta, const float* save_mean, const float* save_rstd,
                       float* dgamma, float* dbeta, float* ws, int batch, int hw, int c,
-                      hipStream_t stream);
+                      hipStream_t stream, SplitSlabs dy_slabs = {});
 
 // ---------------------------------------------------------------- classifier + loss
 // logits[b][n] = sum_k x[b][k] * w[n][k] + bias[n]      (x bf16, w/bias/logits fp32, n <= 16)

@@ -163,14 +163,37 @@ void bn_relu_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const 
                        y, gamma, beta, running_mean, running_var, c, eps, total8);
 }
 
+// The incoming gradient of row r, column group cg: either the stored bf16 tensor, or the sum
+// of a convolution's split slabs - rounded to bf16, stored for the apply pass, and used rounded.
+template <bool SLABS>
+__device__ __forceinline__ void load_dy8(uint16_t* __restrict__ dy, SplitSlabs sl, size_t off,
+                                         float (&g)[8]) {
+    if (SLABS) {
+        float4 lo = *(const float4*)(sl.data + off), hi = *(const float4*)(sl.data + off + 4);
+        for (int s = 1; s < sl.splits; ++s) {
+            const float4 l2 = *(const float4*)(sl.data + s * sl.stride + off);
+            const float4 h2 = *(const float4*)(sl.data + s * sl.stride + off + 4);
+            lo.x += l2.x; lo.y += l2.y; lo.z += l2.z; lo.w += l2.w;
+            hi.x += h2.x; hi.y += h2.y; hi.z += h2.z; hi.w += h2.w;
+        }
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const uint4 pk = pack8(v);
+        *(uint4*)(dy + off) = pk;
+        unpack8(pk, g);
+    } else {
+        unpack8(*(const uint4*)(dy + off), g);
+    }
+}
+
 // -------------------------------------------------------------------------- backward
 // With xh = (x - mean) * rstd, y = gamma*xh + beta and g = dy * [y > 0]:
 //   dbeta = sum g,  dgamma = sum g*xh,  dx = gamma*rstd * (g - dbeta/n - xh*dgamma/n).
+template <bool SLABS>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+    const uint16_t* __restrict__ x, uint16_t* __restrict__ dy,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ ws,
-    int rows, int c, int rows_per_block) {
+    int rows, int c, int rows_per_block, SplitSlabs sl) {
     __shared__ float red[4096];
     // this thread's 8 channels are fixed: y > 0  <=>  x * ysc + ysh > 0, xh = x * rs - mrs
     float rs[8], mrs[8], ysc[8], ysh[8];
@@ -190,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         [&](int r, int cg, float (&a)[8], float (&b)[8]) {
             float v[8], g[8];
             unpack8(*(const uint4*)(x + (size_t)r * c + cg * 8), v);
-            unpack8(*(const uint4*)(dy + (size_t)r * c + cg * 8), g);
+            load_dy8<SLABS>(dy, sl, (size_t)r * c + cg * 8, g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float gi = (__builtin_fmaf(v[i], ysc[i], ysh[i]) > 0.f) ? g[i] : 0.f;
@@ -255,18 +278,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
-void bn_relu_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
                  const float* beta, const float* save_mean, const float* save_rstd,
-                 float* dgamma, float* dbeta, float* ws, int rows, int c, hipStream_t stream) {
+                 float* dgamma, float* dbeta, float* ws, int rows, int c, hipStream_t stream,
+                 SplitSlabs sl) {
     check(rows, c, "bn_relu_bwd");
     const ColReducePlan pl = plan_col_reduce(rows, c);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, dy, gamma,
-                       beta, save_mean, save_rstd, ws, rows, c, pl.rows_per_block);
+    if (sl.splits > 0)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(pl.blocks), dim3(256), 0, stream, x, dy,
+                           gamma, beta, save_mean, save_rstd, ws, rows, c, pl.rows_per_block, sl);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(pl.blocks), dim3(256), 0, stream, x, dy,
+                           gamma, beta, save_mean, save_rstd, ws, rows, c, pl.rows_per_block, sl);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
                        (const float*)ws, dgamma, dbeta, pl.blocks, c);
     const size_t total8 = (size_t)rows * (c / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(total8)), dim3(256), 0, stream, x, dy,
-                       dx, gamma, beta, save_mean, save_rstd, (const float*)dgamma,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(total8)), dim3(256), 0, stream, x,
+                       (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd, (const float*)dgamma,
                        (const float*)dbeta, rows, c, total8);
 }
 
@@ -347,11 +375,12 @@ __device__ __forceinline__ int window_winner(float z0, float z1, float z2, float
     return w;
 }
 
+template <bool SLABS>
 __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(
-    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+    const uint16_t* __restrict__ x, uint16_t* __restrict__ dy,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ ws,
-    int out_rows, int c, int rows_per_block, PoolGeom geo) {
+    int out_rows, int c, int rows_per_block, PoolGeom geo, SplitSlabs sl) {
     __shared__ float red[4096];
     float rs[8], mrs[8], ysc[8], ysh[8];
     {
@@ -370,7 +399,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(
         [&](int r, int cg, float (&a)[8], float (&b)[8]) {
             float v[4][8], g[8];
             load_window(x, geo.in_pixel((size_t)r), cg, c, geo.hw, v);
-            unpack8(*(const uint4*)(dy + (size_t)r * c + cg * 8), g);
+            load_dy8<SLABS>(dy, sl, (size_t)r * c + cg * 8, g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 bool live;
@@ -473,23 +502,29 @@ void bn_relu_pool_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, c
                        x, y, gamma, beta, running_mean, running_var, c, eps, geo, total8);
 }
 
-void bn_relu_pool_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+void bn_relu_pool_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
                       const float* beta, const float* save_mean, const float* save_rstd,
                       float* dgamma, float* dbeta, float* ws, int batch, int hw, int c,
-                      hipStream_t stream) {
+                      hipStream_t stream, SplitSlabs sl) {
     const int rows = batch * hw * hw;
     check(rows, c, "bn_relu_pool_bwd");
     const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_bwd");
     const int out_rows = rows / 4;
     const ColReducePlan pl = plan_col_reduce(out_rows, c);
-    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, dy,
-                       gamma, beta, save_mean, save_rstd, ws, out_rows, c, pl.rows_per_block, geo);
+    if (sl.splits > 0)
+        hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<true>, dim3(pl.blocks), dim3(256), 0, stream, x,
+                           dy, gamma, beta, save_mean, save_rstd, ws, out_rows, c,
+                           pl.rows_per_block, geo, sl);
+    else
+        hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<false>, dim3(pl.blocks), dim3(256), 0, stream,
+                           x, dy, gamma, beta, save_mean, save_rstd, ws, out_rows, c,
+                           pl.rows_per_block, geo, sl);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
                        (const float*)ws, dgamma, dbeta, pl.blocks, c);
     if (!dx) return;        // the caller's next kernel produces dx on the fly (conv1_wgrad_bn_pool)
     const size_t total8 = (size_t)out_rows * (c / 8);
     hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(apply_blocks(total8)), dim3(256), 0, stream,
-                       x, dy, dx, gamma, beta, save_mean, save_rstd, (const float*)dgamma,
+                       x, (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd, (const float*)dgamma,
                        (const float*)dbeta, rows, c, geo, total8);
 }
 

@@ -887,8 +887,14 @@ int conv3x3_igemm_stats_rows(ConvShape s) {
 
 void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
                    const bf16_raw* mask, float* workspace, size_t workspace_elems, ConvShape s,
-                   ConvEpilogue epi, hipStream_t stream, const int* force_plan, float* stats) {
+                   ConvEpilogue epi, hipStream_t stream, const int* force_plan, float* stats,
+                   SplitSlabs* defer) {
     check_shape(s, "conv3x3_igemm");
+    if (defer) {
+        if (epi != EPI_NONE || stats)
+            throw std::invalid_argument("conv3x3_igemm: a deferred slab sum needs the plain epilogue");
+        *defer = SplitSlabs{};
+    }
     if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias)
         throw std::invalid_argument("conv3x3_igemm: bias epilogue without bias");
     if (epi == EPI_MASK && !mask) throw std::invalid_argument("conv3x3_igemm: mask missing");
@@ -936,6 +942,8 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
         hipLaunchKernelGGL(splitk_finish_stats_kernel, dim3(fp.blocks), dim3(256), 0, stream,
                            (const float*)workspace, y, bias, stats, a.M, a.N, pl.splits,
                            (size_t)a.M * a.N, fp.rows_per_block);
+    } else if (pl.splits > 1 && defer) {
+        *defer = SplitSlabs{workspace, pl.splits, (size_t)a.M * a.N};
     } else if (pl.splits > 1) {
         const size_t total4 = (size_t)a.M * a.N / 4;
         hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256),

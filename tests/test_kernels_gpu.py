@@ -340,6 +340,43 @@ def test_bn_relu_pool_fused(c, shape):
     check("bn+pool eval", nchw(ye), refe)
 
 
+@pytest.mark.parametrize("pooled", [False, True])
+def test_bn_backward_sums_split_slabs_itself(pooled):
+    """BatchNorm backward fed the unsummed split-K slabs of the convolution that produced its
+    incoming gradient: bit-identical to summing the slabs first, and the summed bf16 gradient is
+    left where the apply pass (and the caller) expects it."""
+    n = native()
+    C = n.lib()
+    b, hw, c, splits = 16, 4, 256, 3
+    x = (rand_bf16(b, hw, hw, c, scale=2.0, seed=61) + 0.3).to(torch.bfloat16)
+    gamma = torch.rand(c, device=DEV) + 0.5
+    beta = torch.randn(c, device=DEV) * 0.2
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    ohw = hw // 2 if pooled else hw
+    slabs = torch.randn(splits, b, ohw, ohw, c, device=DEV)
+    dy_ref = ((slabs[0] + slabs[1]) + slabs[2]).to(torch.bfloat16)
+    if pooled:
+        _, mean, rstd = n.bn_relu_pool_fwd_train(x, gamma, beta, rm, rv)
+        want = n.bn_relu_pool_bwd(x, dy_ref, gamma, beta, mean, rstd)
+    else:
+        _, mean, rstd = n.bn_relu_fwd_train(x, gamma, beta, rm, rv)
+        want = n.bn_relu_bwd(x, dy_ref, gamma, beta, mean, rstd)
+    dy = torch.zeros_like(dy_ref)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, device=DEV)
+    dbeta = torch.empty(c, device=DEV)
+    ws = torch.empty(C.column_reduce_workspace_elems(), device=DEV)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    args = (x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+            mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr())
+    if pooled:
+        C.bn_relu_pool_bwd(*args, b, hw, c, st, slabs.data_ptr(), splits, slabs[0].numel())
+    else:
+        C.bn_relu_bwd(*args, b * hw * hw, c, st, slabs.data_ptr(), splits, slabs[0].numel())
+    assert torch.equal(dy, dy_ref)
+    assert torch.equal(dx, want[0]) and torch.equal(dgamma, want[1]) and torch.equal(dbeta, want[2])
+
+
 @pytest.mark.parametrize("batch", [2, 64])
 def test_conv1_wgrad_with_bn_pool_backward_on_the_fly(batch):
     """First layer under BatchNorm + ReLU + max-pool: the weight-gradient kernel that forms
