@@ -534,8 +534,11 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                 for (int b : buckets_by_layer_[l])
                     reducer_->bucket_ready(b, wgrad_stream_, bucket_update(b));
             owed.clear();
-            if (fuse_opt && !reducer_) {
-                // the gradients of layers i.. (and the classifier) are final behind the sums
+            if (fuse_opt && !reducer_ && i <= 1) {
+                // The side stream's last hand-off: behind its sums the gradients of every layer
+                // but the first are final, and it would idle while the main stream finishes
+                // the first layer - one update launch for all of them here.  (Slices after
+                // every group were measured slower: they delay the weight gradients behind them.)
                 sgd_slice(layer_begin(i), layer_begin(updated_above), wgrad_stream_);
                 updated_above = i;
             }
