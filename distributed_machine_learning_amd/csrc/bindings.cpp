@@ -49,6 +49,24 @@ PYBIND11_MODULE(_C, m) {
        py::arg("ws_elems"), py::arg("batch"), py::arg("hw"), py::arg("cin"), py::arg("cout"),
        py::arg("epi"), py::arg("stream"), py::arg("bm") = 0, py::arg("bn") = 0,
        py::arg("splits") = 0, py::arg("pm") = -1, py::arg("waves") = 4, py::arg("stats") = 0);
+    // backward-data pass that also leaves the BatchNorm + pool backward sums of the layer whose
+    // pooled gradient it writes; returns the number of partial rows (0: the plan cannot)
+    m.def("conv3x3_igemm_bn_pool", [](uintptr_t x, uintptr_t w, uintptr_t y, uintptr_t ws,
+                                      size_t ws_elems, int batch, int hw, int cin, int cout,
+                                      uintptr_t stream, uintptr_t pre, uintptr_t gamma,
+                                      uintptr_t beta, uintptr_t mean, uintptr_t rstd,
+                                      uintptr_t partials) {
+        BnPoolReduce red;
+        red.pre = ptr<const bf16_raw>(pre);
+        red.gamma = ptr<const float>(gamma); red.beta = ptr<const float>(beta);
+        red.mean = ptr<const float>(mean); red.rstd = ptr<const float>(rstd);
+        red.partials = ptr<float>(partials);
+        BnPartials done;
+        conv3x3_igemm(ptr<const bf16_raw>(x), ptr<const bf16_raw>(w), ptr<bf16_raw>(y), nullptr,
+                      nullptr, ptr<float>(ws), ws_elems, shape(batch, hw, cin, cout), EPI_NONE,
+                      st(stream), nullptr, nullptr, nullptr, &red, &done);
+        return done.data ? done.rows : 0;
+    });
     m.def("conv3x3_igemm_stats_rows", [](int batch, int hw, int cin, int cout) {
         return conv3x3_igemm_stats_rows(shape(batch, hw, cin, cout));
     });

@@ -166,6 +166,10 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
             const size_t n = (size_t)conv3x3_igemm_stats_rows({max_batch_, c.hw, c.cin, c.cout}) *
                              2 * c.cout;
             need = n > need ? n : need;
+            // backward: the dgrad of this layer may leave the previous layer's BatchNorm sums,
+            // one row per pixel tile of at least 64 rows
+            const size_t nbwd = ((size_t)max_batch_ * c.hw * c.hw + 63) / 64 * 2 * c.cin;
+            need = nbwd > need ? nbwd : need;
         }
         w = align_up(w + need);
     }
@@ -461,6 +465,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     if (!side) fire_buckets(nconv, stream);
     else if (bucket_leaves(nconv)) owed.push_back(nconv);
     SplitSlabs pending;     // the arriving gradient is still a split convolution's unsummed slabs
+    BnPartials bn_sums;     // the arriving gradient's BatchNorm backward sums came with it
     for (int i = nconv - 1; i >= 0; --i) {
         const Conv& c = convs_[i];
         const int rows = batch * c.hw * c.hw;
@@ -472,7 +477,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                              params_ + c.gamma_off,
                              params_ + c.beta_off, ws_ + c.save_off, ws_ + c.save_off + c.cout,
                              grads_ + c.gamma_off, grads_ + c.beta_off, ws_ + stats_off_, batch,
-                             c.hw, c.cout, stream, pending);
+                             c.hw, c.cout, stream, pending, bn_sums);
         else if (c.pool_after && !g_on_the_fly)
             maxpool2x2_bwd(arena_ + c.out_off, transit, g, batch, c.hw, c.cout, /*relu_mask=*/true,
                            stream);
@@ -517,11 +522,23 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             ConvShape d = {batch, c.hw, c.cout, c.cin};
             const bool fold_relu = !staged(i - 1);
             // under BatchNorm the consumer is a reduction pass that can sum split slabs itself
+            // ... and when that consumer is a pooled layer, the sums themselves can come out of
+            // this kernel's epilogue (the partial rows reuse the forward statistics scratch)
             pending = SplitSlabs{};
+            bn_sums = BnPartials{};
+            BnPoolReduce red;
+            const bool want_sums = bn_ && prev.pool_after;
+            if (want_sums) {
+                red.pre = arena_ + prev.pre_off;
+                red.gamma = params_ + prev.gamma_off; red.beta = params_ + prev.beta_off;
+                red.mean = ws_ + prev.save_off; red.rstd = ws_ + prev.save_off + prev.cout;
+                red.partials = ws_ + cstats_off_;
+            }
             conv3x3_igemm(g, arena_ + c.wd_off, arriving(i - 1), nullptr,
                           fold_relu ? arena_ + prev.out_off : nullptr, slab, slab_elems_, d,
                           fold_relu ? EPI_MASK : EPI_NONE, stream, nullptr, nullptr,
-                          bn_ ? &pending : nullptr);
+                          bn_ ? &pending : nullptr, want_sums ? &red : nullptr,
+                          want_sums ? &bn_sums : nullptr);
         }
         if (hand) {
             check_hip(hipStreamWaitEvent(wgrad_stream_, hand_off_[i], 0), "hipStreamWaitEvent(hand-off)");

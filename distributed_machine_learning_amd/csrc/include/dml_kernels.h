@@ -36,33 +36,6 @@ struct ConvShape {
     int cout;    // output channels of the GEMM (multiple of 64)
 };
 
-// Implicit GEMM  y[m][n] = sum_{tap,c} x[m (+) tap][c] * w[n][tap][c],  m = (b,h,w) NHWC.
-// Forward: x = activations, w = weights [cout][9][cin].  Backward-data: x = dy,
-// w = repacked weights [cin][9 flipped][cout] (see repack_dgrad_weights), roles of
-// cin/cout swapped by the caller.  `workspace` (fp32, >= splits*M*N elements) is used
-// when the launcher decides to split the reduction over taps.
-// Partial results of a convolution that split its reduction: `splits` fp32 slabs of the
-// output, `stride` elements apart, still to be summed (splits == 0: nothing pending).
-struct SplitSlabs {
-    const float* data = nullptr;
-    int splits = 0;
-    size_t stride = 0;
-};
-// `defer` (EPI_NONE only): when the launcher splits the reduction, leave the sum of the slabs to
-// the consumer (a BatchNorm backward reduction reads the result anyway) and describe them in
-// *defer instead of launching the finishing kernel; y is then NOT written.
-void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
-                   const bf16_raw* mask, float* workspace, size_t workspace_elems,
-                   ConvShape s, ConvEpilogue epi, hipStream_t stream,
-                   const int* force_plan = nullptr /* tuning: {BM, BN, splits, position-major (-1 auto), waves} */,
-                   float* stats = nullptr, SplitSlabs* defer = nullptr);
-size_t conv3x3_igemm_workspace_elems(ConvShape s);
-// With `stats` (EPI_BIAS, default plan) the kernel also leaves per-tile column sums and sums
-// of squares of the BIAS-FREE output: stats[row][0][n], stats[row][1][n] for
-// conv3x3_igemm_stats_rows(s) rows - the BatchNorm statistics without another pass over y
-// (see BnPartials).
-int conv3x3_igemm_stats_rows(ConvShape s);
-
 // Column partial sums handed from a producer kernel to BatchNorm: `rows` rows of [2][c]
 // floats; the mean is shifted by `shift[c]` (the conv bias the partials leave out).
 struct BnPartials {
@@ -70,6 +43,48 @@ struct BnPartials {
     int rows = 0;
     const float* shift = nullptr;
 };
+
+// Partial results of a convolution that split its reduction: `splits` fp32 slabs of the
+// output, `stride` elements apart, still to be summed (splits == 0: nothing pending).
+struct SplitSlabs {
+    const float* data = nullptr;
+    int splits = 0;
+    size_t stride = 0;
+};
+// Backward of "conv -> BatchNorm -> ReLU -> 2x2 max-pool" for the layer whose POOLED output
+// gradient this convolution (a backward-data pass) produces: with `bn_pool` the kernel's
+// epilogue also computes that layer's BatchNorm backward sums (dbeta = sum g, dgamma = sum g*xh
+// over the pooling winners) from its fp32 accumulators and the layer's stored conv output, one
+// partial row per pixel tile in `partials` ([tile][2][N] floats) - the reduction pass of
+// bn_relu_pool_bwd, which would re-read this gradient and the conv output, is then not needed.
+// Applied only by plans that keep a pixel tile in one block (reported through *bn_done).
+struct BnPoolReduce {
+    const bf16_raw* pre = nullptr;      // the pooled layer's conv output [batch][2hw][2hw][N]
+    const float *gamma = nullptr, *beta = nullptr, *mean = nullptr, *rstd = nullptr;
+    float* partials = nullptr;
+};
+
+// Implicit GEMM  y[m][n] = sum_{tap,c} x[m (+) tap][c] * w[n][tap][c],  m = (b,h,w) NHWC.
+// Forward: x = activations, w = weights [cout][9][cin].  Backward-data: x = dy,
+// w = repacked weights [cin][9 flipped][cout] (see repack_dgrad_weights), roles of
+// cin/cout swapped by the caller.  `workspace` (fp32, >= splits*M*N elements) is used
+// when the launcher decides to split the reduction over taps.
+// `defer` (EPI_NONE only): when the launcher splits the reduction, leave the sum of the slabs to
+// the consumer (a BatchNorm backward reduction reads the result anyway) and describe them in
+// *defer instead of launching the finishing kernel; y is then NOT written.
+void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
+                   const bf16_raw* mask, float* workspace, size_t workspace_elems,
+                   ConvShape s, ConvEpilogue epi, hipStream_t stream,
+                   const int* force_plan = nullptr /* tuning: {BM, BN, splits, position-major (-1 auto), waves} */,
+                   float* stats = nullptr, SplitSlabs* defer = nullptr,
+                   const BnPoolReduce* bn_pool = nullptr, BnPartials* bn_done = nullptr);
+size_t conv3x3_igemm_workspace_elems(ConvShape s);
+// With `stats` (EPI_BIAS, default plan) the kernel also leaves per-tile column sums and sums
+// of squares of the BIAS-FREE output: stats[row][0][n], stats[row][1][n] for
+// conv3x3_igemm_stats_rows(s) rows - the BatchNorm statistics without another pass over y
+// (see BnPartials).
+int conv3x3_igemm_stats_rows(ConvShape s);
+
 
 // First layer: x is [B,32,32,4] bf16 (3 channels + zero pad), w1 is [64][64] bf16 with
 // k = tap*4 + c (k >= 36 zero), y = relu?(conv + bias) as [B,32,32,64] bf16.
@@ -179,7 +194,9 @@ void bn_relu_pool_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, c
 void bn_relu_pool_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
                       const float* beta, const float* save_mean, const float* save_rstd,
                       float* dgamma, float* dbeta, float* ws, int batch, int hw, int c,
-                      hipStream_t stream, SplitSlabs dy_slabs = {});
+                      hipStream_t stream, SplitSlabs dy_slabs = {}, BnPartials sums = {});
+// (`sums`: the dbeta / dgamma partial rows were already produced by the convolution that wrote
+// dy, see BnPoolReduce - the reduction pass is skipped)
 
 // ---------------------------------------------------------------- classifier + loss
 // logits[b][n] = sum_k x[b][k] * w[n][k] + bias[n]      (x bf16, w/bias/logits fp32, n <= 16)

@@ -505,22 +505,30 @@ void bn_relu_pool_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, c
 void bn_relu_pool_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
                       const float* beta, const float* save_mean, const float* save_rstd,
                       float* dgamma, float* dbeta, float* ws, int batch, int hw, int c,
-                      hipStream_t stream, SplitSlabs sl) {
+                      hipStream_t stream, SplitSlabs sl, BnPartials sums) {
     const int rows = batch * hw * hw;
     check(rows, c, "bn_relu_pool_bwd");
     const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_bwd");
     const int out_rows = rows / 4;
     const ColReducePlan pl = plan_col_reduce(out_rows, c);
-    if (sl.splits > 0)
+    int nb = pl.blocks;
+    const float* partials = ws;
+    if (sums.data) {            // the producer of dy already left the sums, one partial row per tile
+        if (sl.splits > 0 || sums.rows <= 0)
+            throw std::invalid_argument("bn_relu_pool_bwd: inconsistent partial sums");
+        nb = sums.rows;
+        partials = sums.data;
+    } else if (sl.splits > 0) {
         hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<true>, dim3(pl.blocks), dim3(256), 0, stream, x,
                            dy, gamma, beta, save_mean, save_rstd, ws, out_rows, c,
                            pl.rows_per_block, geo, sl);
-    else
+    } else {
         hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<false>, dim3(pl.blocks), dim3(256), 0, stream,
                            x, dy, gamma, beta, save_mean, save_rstd, ws, out_rows, c,
                            pl.rows_per_block, geo, sl);
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
-                       (const float*)ws, dgamma, dbeta, pl.blocks, c);
+    }
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream, partials,
+                       dgamma, dbeta, nb, c);
     if (!dx) return;        // the caller's next kernel produces dx on the fly (conv1_wgrad_bn_pool)
     const size_t total8 = (size_t)out_rows * (c / 8);
     hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(apply_blocks(total8)), dim3(256), 0, stream,

@@ -62,6 +62,10 @@ struct IgemmArgs {
     int batch, img_blocks;   // position-major tiling: images, and tiles per spatial position
     unsigned x_bytes;     // extents for the buffer descriptors (out-of-range loads return 0)
     unsigned w_bytes;
+    // optional BatchNorm+pool backward sums in the epilogue (see BnPoolReduce): the pooled
+    // layer's conv output and constants; the partial rows go to `stats`
+    const uint16_t* bn_pre;
+    const float *bn_gamma, *bn_beta, *bn_mean, *bn_rstd;
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -136,6 +140,69 @@ __device__ __forceinline__ void store_lane_channels(const f32x4 (&a)[TN], uint16
 #pragma unroll
         for (int i = 0; i < TN; ++i) *(uint2*)(y + off + 4 * i) = make_uint2(o[2 * i], o[2 * i + 1]);
     }
+}
+
+// BatchNorm + ReLU + pool backward sums of one wave's accumulator tile (see BnPoolReduce): the
+// tile holds the gradient of the POOLED activation; lane = pooled pixel m_first + 16*j and the
+// 4*TN consecutive channels from nl.  Per element the pooling winner is re-derived from the
+// layer's conv output (first maximum, strict comparisons, the fma of the forward pass) and the
+// bf16-rounded gradient counts if the winner is positive.  Returns the sums over the tile's 16*TM
+// pixels in every lane of a 16-lane row group: s1 = sum g, s2 = sum g * xh.
+template <int TN, int TM>
+__device__ __forceinline__ void bn_pool_bwd_tile_sums(const f32x4 (&acc)[TN][TM], const IgemmArgs& p,
+                                                      int m_first, int nl, float (&s1)[TN][4],
+                                                      float (&s2)[TN][4]) {
+    const int hw = p.hw, in_hw = 2 * p.hw;
+    float ysc[TN][4], ysh[TN][4], rs[TN][4], mrs[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = nl + 4 * i + c;
+            rs[i][c] = p.bn_rstd[col];
+            mrs[i][c] = p.bn_mean[col] * rs[i][c];
+            ysc[i][c] = p.bn_gamma[col] * rs[i][c];
+            ysh[i][c] = __builtin_fmaf(-p.bn_gamma[col], mrs[i][c], p.bn_beta[col]);
+            s1[i][c] = s2[i][c] = 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m_first + j * 16;          // pooled pixel
+        if (m >= p.M) continue;
+        const int ox = m & (hw - 1), oy = (m >> p.log_hw) & (hw - 1);
+        const size_t b = (size_t)(m >> (2 * p.log_hw));
+        const uint16_t* win = p.bn_pre + (((b * in_hw + 2 * oy) * in_hw + 2 * ox) * p.N + nl);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const uint16_t* w0 = win + 4 * i;
+            const uint2 q[4] = {*(const uint2*)w0, *(const uint2*)(w0 + p.N),
+                                *(const uint2*)(w0 + (size_t)in_hw * p.N),
+                                *(const uint2*)(w0 + (size_t)in_hw * p.N + p.N)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float best = 0.f, xw = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t word = c < 2 ? q[k].x : q[k].y;
+                    const float v =
+                        bf16_bits_to_float((uint16_t)((c & 1) ? (word >> 16) : (word & 0xffff)));
+                    const float z = __builtin_fmaf(v, ysc[i][c], ysh[i][c]);
+                    if (k == 0 || z > best) { best = z; xw = v; }
+                }
+                const float d = bf16_bits_to_float(float_to_bf16_bits(acc[i][j][c]));
+                const float gi = best > 0.f ? d : 0.f;
+                s1[i][c] += gi;
+                s2[i][c] += gi * __builtin_fmaf(xw, rs[i][c], -mrs[i][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s1[i][c] = row16_sum(s1[i][c]);
+            s2[i][c] = row16_sum(s2[i][c]);
+        }
 }
 
 // PM ("position-major") tiling: the BM rows of a tile are BM consecutive IMAGES at ONE
@@ -346,26 +413,37 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
         mma(wfb, xfb);
     }
 
-    // ---- BatchNorm statistics for free: column sums (and sums of squares) of this tile's
+    // ---- BatchNorm sums for free, one partial row [2][N] per pixel tile (a fold kernel sums
+    // the tiles).  Forward (p.stats, EPI_BIAS): column sums and sums of squares of this tile's
     // fp32 accumulators, i.e. of the output without its bias (the consumer shifts the mean by
-    // the bias; the variance does not care).  Rows past the end were fed zeros and add
-    // nothing.  One partial row per tile; a fold kernel sums the tiles.
-    if (!SPLIT && p.stats) {
+    // the bias; the variance does not care).  Backward (p.bn_pre, a dgrad pass whose output is
+    // the gradient of a BatchNorm + ReLU + pool layer's POOLED activation): that layer's dbeta /
+    // dgamma sums - per output element the pooling winner is re-derived from the layer's conv
+    // output (first maximum, strict comparisons, the fma of the forward pass), the bf16-rounded
+    // gradient goes to it if it is positive.  Rows past the end add nothing.
+    const bool bn_bwd = EPI == EPI_NONE && !SPLIT && !PM && p.bn_pre != nullptr;
+    if (!SPLIT && p.stats && (EPI == EPI_BIAS || bn_bwd)) {
         float s1[TN][4], s2[TN][4];
+        if (bn_bwd) {
+            if constexpr (EPI == EPI_NONE && !SPLIT && !PM)
+                bn_pool_bwd_tile_sums<TN, TM>(acc, p, m0 + wm * WTM + l15,
+                                              n0 + wn * WTN + lq * 4 * TN, s1, s2);
+        } else {
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float a = 0.f, b = 0.f;
+                for (int c = 0; c < 4; ++c) {
+                    float a = 0.f, b = 0.f;
 #pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    const float v = acc[i][j][c];
-                    a += v;
-                    b += v * v;
+                    for (int j = 0; j < TM; ++j) {
+                        const float v = acc[i][j][c];
+                        a += v;
+                        b += v * v;
+                    }
+                    s1[i][c] = row16_sum(a);
+                    s2[i][c] = row16_sum(b);
                 }
-                s1[i][c] = row16_sum(a);
-                s2[i][c] = row16_sum(b);
-            }
+        }
         __syncthreads();                       // every wave is done with the operand stages
         float* red = (float*)smem;             // [WAVES_M][2][BN]
         if (l15 == 0) {
@@ -771,22 +849,29 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(IgemmArgs p) {
         }
     }
 
-    if (p.stats) {
+    const bool bn_bwd = EPI == EPI_NONE && p.bn_pre != nullptr;
+    if (p.stats && (EPI == EPI_BIAS || bn_bwd)) {
         float s1[TN][4], s2[TN][4];
+        if (bn_bwd) {
+            if constexpr (EPI == EPI_NONE)
+                bn_pool_bwd_tile_sums<TN, TM>(acc, p, m0 + wm * WTM + l15,
+                                              n0 + wn * WTN + lq * 4 * TN, s1, s2);
+        } else {
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float a = 0.f, b = 0.f;
+                for (int c = 0; c < 4; ++c) {
+                    float a = 0.f, b = 0.f;
 #pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    const float v = acc[i][j][c];
-                    a += v;
-                    b += v * v;
+                    for (int j = 0; j < TM; ++j) {
+                        const float v = acc[i][j][c];
+                        a += v;
+                        b += v * v;
+                    }
+                    s1[i][c] = row16_sum(a);
+                    s2[i][c] = row16_sum(b);
                 }
-                s1[i][c] = row16_sum(a);
-                s2[i][c] = row16_sum(b);
-            }
+        }
         __syncthreads();
         float* red = (float*)smem;             // [WAVES_M][2][BN]
         if (l15 == 0) {
@@ -888,8 +973,12 @@ int conv3x3_igemm_stats_rows(ConvShape s) {
 void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
                    const bf16_raw* mask, float* workspace, size_t workspace_elems, ConvShape s,
                    ConvEpilogue epi, hipStream_t stream, const int* force_plan, float* stats,
-                   SplitSlabs* defer) {
+                   SplitSlabs* defer, const BnPoolReduce* bn_pool, BnPartials* bn_done) {
     check_shape(s, "conv3x3_igemm");
+    if (bn_done) *bn_done = BnPartials{};
+    if (bn_pool && (epi != EPI_NONE || stats || !bn_done || !bn_pool->pre || !bn_pool->partials))
+        throw std::invalid_argument("conv3x3_igemm: BatchNorm backward sums need the plain epilogue, "
+                                    "a partials buffer and bn_done");
     if (defer) {
         if (epi != EPI_NONE || stats)
             throw std::invalid_argument("conv3x3_igemm: a deferred slab sum needs the plain epilogue");
@@ -901,6 +990,7 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
     IgemmArgs a;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.mask = mask; a.slab = workspace;
     a.stats = stats;
+    a.bn_pre = nullptr; a.bn_gamma = a.bn_beta = a.bn_mean = a.bn_rstd = nullptr;
     if (stats && (epi != EPI_BIAS || force_plan))
         throw std::invalid_argument("conv3x3_igemm: statistics come with the default plan and "
                                     "the bias-only epilogue");
@@ -919,6 +1009,14 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
         const size_t need = (size_t)pl.splits * a.M * a.N;
         if (!workspace || workspace_elems < need)
             throw std::invalid_argument("conv3x3_igemm: workspace too small for the tap split");
+    }
+    // BatchNorm backward sums in the epilogue: plans whose block owns a whole pixel tile, NHWC rows
+    if (bn_pool && pl.splits == 1 && !pl.pm) {
+        a.bn_pre = bn_pool->pre;
+        a.bn_gamma = bn_pool->gamma; a.bn_beta = bn_pool->beta;
+        a.bn_mean = bn_pool->mean; a.bn_rstd = bn_pool->rstd;
+        a.stats = bn_pool->partials;
+        *bn_done = BnPartials{bn_pool->partials, (a.M + pl.bm - 1) / pl.bm, nullptr};
     }
     if (pl.waves == 16) {
         if (pl.splits != 1 || pl.pm || pl.bm == pl.bn - 64)

@@ -340,6 +340,42 @@ def test_bn_relu_pool_fused(c, shape):
     check("bn+pool eval", nchw(ye), refe)
 
 
+@pytest.mark.parametrize("batch,hw,cin,cout", [(64, 16, 128, 64), (256, 8, 256, 128)])
+def test_dgrad_epilogue_leaves_bn_pool_backward_sums(batch, hw, cin, cout):
+    """A backward-data convolution whose output is the gradient of a BatchNorm + ReLU + pool
+    layer's pooled activation: the dbeta / dgamma partial rows of its epilogue must fold to what
+    the stand-alone reduction pass computes from the stored gradient (same per-element terms,
+    another summation order), and the gradient itself must be unchanged."""
+    n = native()
+    C = n.lib()
+    st = int(torch.cuda.current_stream().cuda_stream)
+    # consumer layer: `cout` channels at 2*hw, pooled to hw; this conv maps cin -> cout at hw
+    pre = (rand_bf16(batch, 2 * hw, 2 * hw, cout, scale=2.0, seed=71) + 0.3).to(torch.bfloat16)
+    gamma = torch.rand(cout, device=DEV) + 0.5
+    beta = torch.randn(cout, device=DEV) * 0.2
+    rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    _, mean, rstd = n.bn_relu_pool_fwd_train(pre, gamma, beta, rm, rv)
+    x = rand_bf16(batch, hw, hw, cin, seed=72)
+    w = (torch.randn(cout, 3, 3, cin, device=DEV) * 0.05).to(torch.bfloat16)
+    ws_elems = C.conv3x3_igemm_workspace_elems(batch, hw, cin, cout)
+    ws = torch.empty(max(ws_elems, 1), device=DEV)
+    y_ref = torch.empty(batch, hw, hw, cout, dtype=torch.bfloat16, device=DEV)
+    C.conv3x3_igemm(x.data_ptr(), w.data_ptr(), y_ref.data_ptr(), 0, 0, ws.data_ptr(), ws_elems,
+                    batch, hw, cin, cout, 0, st)
+    y = torch.empty_like(y_ref)
+    partials = torch.zeros(batch * hw * hw // 64 * 2 * cout, device=DEV)
+    rows = C.conv3x3_igemm_bn_pool(x.data_ptr(), w.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_elems,
+                                   batch, hw, cin, cout, st, pre.data_ptr(), gamma.data_ptr(),
+                                   beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                   partials.data_ptr())
+    assert rows > 0, "this shape should take a plan that owns whole pixel tiles"
+    assert torch.equal(y, y_ref)
+    sums = partials[:rows * 2 * cout].view(rows, 2, cout).double().sum(0)
+    _, dgamma, dbeta = n.bn_relu_pool_bwd(pre, y_ref, gamma, beta, mean, rstd)
+    check("dbeta from the dgrad epilogue", sums[0].float(), dbeta, rtol=1e-4, atol_scale=1e-4)
+    check("dgamma from the dgrad epilogue", sums[1].float(), dgamma, rtol=1e-4, atol_scale=1e-4)
+
+
 @pytest.mark.parametrize("pooled", [False, True])
 def test_bn_backward_sums_split_slabs_itself(pooled):
     """BatchNorm backward fed the unsummed split-K slabs of the convolution that produced its
