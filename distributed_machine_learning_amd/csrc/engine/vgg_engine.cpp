@@ -526,6 +526,9 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             // this kernel's epilogue (the partial rows reuse the forward statistics scratch)
             pending = SplitSlabs{};
             bn_sums = BnPartials{};
+            // (a consumer small enough for the one-launch BatchNorm backward wants a stored tensor)
+            const bool defer_sum = bn_ && !bn_bwd_single_launch(
+                batch * c.hw * c.hw, c.cin);
             BnPoolReduce red;
             const bool want_sums = bn_ && prev.pool_after;
             if (want_sums) {
@@ -537,7 +540,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             conv3x3_igemm(g, arena_ + c.wd_off, arriving(i - 1), nullptr,
                           fold_relu ? arena_ + prev.out_off : nullptr, slab, slab_elems_, d,
                           fold_relu ? EPI_MASK : EPI_NONE, stream, nullptr, nullptr,
-                          bn_ ? &pending : nullptr, want_sums ? &red : nullptr,
+                          defer_sum ? &pending : nullptr, want_sums ? &red : nullptr,
                           want_sums ? &bn_sums : nullptr);
         }
         if (hand) {

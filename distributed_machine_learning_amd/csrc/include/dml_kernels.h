@@ -180,6 +180,10 @@ void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gam
                  float* dgamma, float* dbeta, float* stats_ws, int rows, int c,
                  hipStream_t stream, SplitSlabs dy_slabs = {});
 
+// True when bn_relu_bwd / bn_relu_pool_bwd handle a gradient of `dy_rows` rows x c channels in a
+// single launch (small layers) - provided dy is a stored tensor, not unsummed split slabs.
+bool bn_bwd_single_launch(int dy_rows, int c);
+
 // BatchNorm + ReLU + 2x2/2 max-pool in one pass each way (x is the conv output
 // [batch][hw][hw][c], y / dy the pooled tensor [batch][hw/2][hw/2][c]).  The full-resolution
 // activation and its gradient are never materialised: backward recomputes the winning

@@ -278,11 +278,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
+// (small layers: one launch, defined with its kernel further down)
+bool bn_relu_bwd_small(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
+                       const float* beta, const float* save_mean, const float* save_rstd,
+                       float* dgamma, float* dbeta, int rows, int c, hipStream_t stream,
+                       SplitSlabs sl);
+
 void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
                  const float* beta, const float* save_mean, const float* save_rstd,
                  float* dgamma, float* dbeta, float* ws, int rows, int c, hipStream_t stream,
                  SplitSlabs sl) {
     check(rows, c, "bn_relu_bwd");
+    if (bn_relu_bwd_small(x, dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, rows, c,
+                          stream, sl))
+        return;
     const ColReducePlan pl = plan_col_reduce(rows, c);
     if (sl.splits > 0)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(pl.blocks), dim3(256), 0, stream, x, dy,
@@ -466,6 +475,159 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
     }
 }
 
+// ------------------------------------------- small layers: backward in ONE launch
+// The three-kernel scheme (partial sums, fold, apply) exists because a column has more rows
+// than one block can stream.  On the last layers (<= 256 gradient rows: a fraction of a MB)
+// the data is nothing and the three dependent launches are everything, so a block
+// takes 16 channels and ALL rows instead: wave = 8 channels x 64 row lanes, sums by DPP and a
+// 4-entry LDS exchange - the block then HAS dgamma / dbeta - and applies straight away (the
+// second read of x / dy comes out of cache).  Fixed summation order: bit-reproducible.
+template <bool POOL, bool SLABS>
+__global__ __launch_bounds__(256) void bn_bwd_slab_kernel(
+    const uint16_t* __restrict__ x, uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int rows, int c, float inv_n, PoolGeom geo, SplitSlabs sl) {
+    __shared__ float xch[4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rl = threadIdx.x & 127;                       // row lane 0..127
+    const int cg = blockIdx.x * 2 + (wave >> 1);            // 8-channel group
+    const int col0 = cg * 8;
+    float rs[8], mrs[8], ysc[8], ysh[8], gm[8];
+    {
+        float bt[8], mn[8];
+        load_consts(rstd, col0, rs); load_consts(mean, col0, mn);
+        load_consts(gamma, col0, gm); load_consts(beta, col0, bt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mrs[i] = mn[i] * rs[i];
+            ysc[i] = gm[i] * rs[i];
+            ysh[i] = __builtin_fmaf(-gm[i], mrs[i], bt[i]);
+        }
+    }
+    float a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = b[i] = 0.f;
+    for (int r = rl; r < rows; r += 128) {
+        float g[8];
+        load_dy8<SLABS>(dy, sl, (size_t)r * c + col0, g);
+        if (POOL) {
+            float v[4][8];
+            load_window(x, geo.in_pixel((size_t)r), cg, c, geo.hw, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bool live;
+                const int w = window_winner(__builtin_fmaf(v[0][i], ysc[i], ysh[i]),
+                                            __builtin_fmaf(v[1][i], ysc[i], ysh[i]),
+                                            __builtin_fmaf(v[2][i], ysc[i], ysh[i]),
+                                            __builtin_fmaf(v[3][i], ysc[i], ysh[i]), live);
+                const float xv = w == 0 ? v[0][i] : w == 1 ? v[1][i] : w == 2 ? v[2][i] : v[3][i];
+                const float gi = live ? g[i] : 0.f;
+                a[i] += gi;
+                b[i] += gi * (xv * rs[i] - mrs[i]);
+            }
+        } else {
+            float v[8];
+            unpack8(*(const uint4*)(x + (size_t)r * c + col0), v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float gi = (__builtin_fmaf(v[i], ysc[i], ysh[i]) > 0.f) ? g[i] : 0.f;
+                a[i] += gi;
+                b[i] += gi * (v[i] * rs[i] - mrs[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = wave_sum_dpp(a[i]);
+        b[i] = wave_sum_dpp(b[i]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            xch[wave][i] = a[i];
+            xch[wave][8 + i] = b[i];
+        }
+    }
+    __syncthreads();
+    const int w0 = wave & 2;            // the two waves of this channel group
+    float k1[8], k2[8], k3[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float db = xch[w0][i] + xch[w0 + 1][i];
+        const float dg = xch[w0][8 + i] + xch[w0 + 1][8 + i];
+        if (threadIdx.x == w0 * 64) {
+            dbeta[col0 + i] = db;
+            dgamma[col0 + i] = dg;
+        }
+        k1[i] = gm[i] * rs[i];
+        const float dgn = dg * inv_n, dbn = db * inv_n;
+        k2[i] = k1[i] * __builtin_fmaf(-mrs[i], dgn, dbn);
+        k3[i] = (k1[i] * rs[i]) * dgn;
+    }
+    for (int r = rl; r < rows; r += 128) {
+        float g[8];
+        unpack8(*(const uint4*)(dy + (size_t)r * c + col0), g);
+        if (POOL) {
+            float v[4][8], o[4][8];
+            const size_t ipix = geo.in_pixel((size_t)r);
+            load_window(x, ipix, cg, c, geo.hw, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bool live;
+                const int w = window_winner(__builtin_fmaf(v[0][i], ysc[i], ysh[i]),
+                                            __builtin_fmaf(v[1][i], ysc[i], ysh[i]),
+                                            __builtin_fmaf(v[2][i], ysc[i], ysh[i]),
+                                            __builtin_fmaf(v[3][i], ysc[i], ysh[i]), live);
+                const float gk = live ? k1[i] * g[i] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    o[q][i] = __builtin_fmaf(-k3[i], v[q][i], (w == q ? gk : 0.f) - k2[i]);
+            }
+            uint16_t* p = dx + ipix * c + col0;
+            *(uint4*)(p) = pack8(o[0]);
+            *(uint4*)(p + c) = pack8(o[1]);
+            *(uint4*)(p + (size_t)geo.hw * c) = pack8(o[2]);
+            *(uint4*)(p + (size_t)geo.hw * c + c) = pack8(o[3]);
+        } else {
+            float v[8], o[8];
+            unpack8(*(const uint4*)(x + (size_t)r * c + col0), v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float gi = (__builtin_fmaf(v[i], ysc[i], ysh[i]) > 0.f) ? g[i] : 0.f;
+                o[i] = k1[i] * gi - k2[i] - k3[i] * v[i];
+            }
+            *(uint4*)(dx + (size_t)r * c + col0) = pack8(o);
+        }
+    }
+}
+
+// rows of the incoming gradient up to which the one-launch kernel is used (measured at 512
+// channels: a win at 256 rows, a loss at 1024 - 32 blocks do not stream 2-4 MB fast enough)
+constexpr int kSlabKernelMaxRows = 256;
+inline bool use_slab_kernel(int dy_rows, int c) { return dy_rows <= kSlabKernelMaxRows && c % 16 == 0 && c >= 256; }
+
+bool bn_relu_bwd_small(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
+                       const float* beta, const float* save_mean, const float* save_rstd,
+                       float* dgamma, float* dbeta, int rows, int c, hipStream_t stream,
+                       SplitSlabs sl) {
+    // (not for unsummed split slabs: 9 fp32 slabs are real bytes, 32 blocks cannot stream them)
+    if (!use_slab_kernel(rows, c) || sl.splits > 0) return false;
+    const PoolGeom none = {c / 8, 0, 0};
+    const float inv_n = 1.f / (float)rows;
+    if (sl.splits > 0)
+        hipLaunchKernelGGL((bn_bwd_slab_kernel<false, true>), dim3(c / 16), dim3(256), 0, stream, x,
+                           dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, rows, c, inv_n,
+                           none, sl);
+    else
+        hipLaunchKernelGGL((bn_bwd_slab_kernel<false, false>), dim3(c / 16), dim3(256), 0, stream, x,
+                           dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, rows, c, inv_n,
+                           none, sl);
+    return true;
+}
+
+bool bn_bwd_single_launch(int dy_rows, int c) { return use_slab_kernel(dy_rows, c); }
+
 namespace {
 PoolGeom pool_geom(int batch, int hw, int c, const char* who) {
     if (batch <= 0 || hw < 2 || hw > 64 || (hw & (hw - 1)))
@@ -510,6 +672,18 @@ void bn_relu_pool_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float
     check(rows, c, "bn_relu_pool_bwd");
     const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_bwd");
     const int out_rows = rows / 4;
+    if (!sums.data && dx && sl.splits == 0 && use_slab_kernel(out_rows, c)) {
+        const float inv_n = 1.f / (float)rows;
+        if (sl.splits > 0)
+            hipLaunchKernelGGL((bn_bwd_slab_kernel<true, true>), dim3(c / 16), dim3(256), 0, stream, x,
+                               dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, out_rows, c,
+                               inv_n, geo, sl);
+        else
+            hipLaunchKernelGGL((bn_bwd_slab_kernel<true, false>), dim3(c / 16), dim3(256), 0, stream,
+                               x, dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, out_rows,
+                               c, inv_n, geo, sl);
+        return;
+    }
     const ColReducePlan pl = plan_col_reduce(out_rows, c);
     int nb = pl.blocks;
     const float* partials = ws;
