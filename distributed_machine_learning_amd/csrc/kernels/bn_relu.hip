@@ -482,17 +482,35 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
 // takes 16 channels and ALL rows instead: wave = 8 channels x 64 row lanes, sums by DPP and a
 // 4-entry LDS exchange - the block then HAS dgamma / dbeta - and applies straight away (the
 // second read of x / dy comes out of cache).  Fixed summation order: bit-reproducible.
-template <bool POOL, bool SLABS>
+template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_slab_kernel(
-    const uint16_t* __restrict__ x, uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int rows, int c, float inv_n, PoolGeom geo, SplitSlabs sl) {
+    float* __restrict__ dbeta, int rows, int c, float inv_n, PoolGeom geo) {
+    constexpr int R = 2;                // rows per lane: rows <= 256, everything stays in registers
+    constexpr int W = POOL ? 4 : 1;     // conv-output positions per gradient row
     __shared__ float xch[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rl = threadIdx.x & 127;                       // row lane 0..127
     const int cg = blockIdx.x * 2 + (wave >> 1);            // 8-channel group
     const int col0 = cg * 8;
+    // every global load of the kernel is issued here, before anything waits
+    uint4 gq[R], vq[R][W];
+    size_t xoff[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int r = rl + 128 * k;
+        const int rc = r < rows ? r : 0;
+        gq[k] = *(const uint4*)(dy + (size_t)rc * c + col0);
+        xoff[k] = (POOL ? geo.in_pixel((size_t)rc) : (size_t)rc) * c + col0;
+        vq[k][0] = *(const uint4*)(x + xoff[k]);
+        if (POOL) {
+            vq[k][1] = *(const uint4*)(x + xoff[k] + c);
+            vq[k][2] = *(const uint4*)(x + xoff[k] + (size_t)geo.hw * c);
+            vq[k][3] = *(const uint4*)(x + xoff[k] + (size_t)geo.hw * c + c);
+        }
+    }
     float rs[8], mrs[8], ysc[8], ysh[8], gm[8];
     {
         float bt[8], mn[8];
@@ -505,36 +523,30 @@ __global__ __launch_bounds__(256) void bn_bwd_slab_kernel(
             ysh[i] = __builtin_fmaf(-gm[i], mrs[i], bt[i]);
         }
     }
+    float g[R][8], v[R][W][8];
+    int win[R][8];                      // winning window position, -1: nothing passes
     float a[8], b[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = b[i] = 0.f;
-    for (int r = rl; r < rows; r += 128) {
-        float g[8];
-        load_dy8<SLABS>(dy, sl, (size_t)r * c + col0, g);
-        if (POOL) {
-            float v[4][8];
-            load_window(x, geo.in_pixel((size_t)r), cg, c, geo.hw, v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                bool live;
-                const int w = window_winner(__builtin_fmaf(v[0][i], ysc[i], ysh[i]),
-                                            __builtin_fmaf(v[1][i], ysc[i], ysh[i]),
-                                            __builtin_fmaf(v[2][i], ysc[i], ysh[i]),
-                                            __builtin_fmaf(v[3][i], ysc[i], ysh[i]), live);
-                const float xv = w == 0 ? v[0][i] : w == 1 ? v[1][i] : w == 2 ? v[2][i] : v[3][i];
-                const float gi = live ? g[i] : 0.f;
-                a[i] += gi;
-                b[i] += gi * (xv * rs[i] - mrs[i]);
-            }
-        } else {
-            float v[8];
-            unpack8(*(const uint4*)(x + (size_t)r * c + col0), v);
+    for (int k = 0; k < R; ++k) {
+        const bool valid = rl + 128 * k < rows;
+        unpack8(gq[k], g[k]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float gi = (__builtin_fmaf(v[i], ysc[i], ysh[i]) > 0.f) ? g[i] : 0.f;
-                a[i] += gi;
-                b[i] += gi * (v[i] * rs[i] - mrs[i]);
+        for (int q = 0; q < W; ++q) unpack8(vq[k][q], v[k][q]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int w = 0;
+            float m = __builtin_fmaf(v[k][0][i], ysc[i], ysh[i]), xv = v[k][0][i];
+#pragma unroll
+            for (int q = 1; q < W; ++q) {
+                const float z = __builtin_fmaf(v[k][q][i], ysc[i], ysh[i]);
+                if (z > m) { m = z; w = q; xv = v[k][q][i]; }
             }
+            win[k][i] = (valid && m > 0.f) ? w : -1;
+            const float gi = win[k][i] >= 0 ? g[k][i] : 0.f;
+            a[i] += gi;
+            b[i] += gi * (xv * rs[i] - mrs[i]);
         }
     }
 #pragma unroll
@@ -565,39 +577,23 @@ __global__ __launch_bounds__(256) void bn_bwd_slab_kernel(
         k2[i] = k1[i] * __builtin_fmaf(-mrs[i], dgn, dbn);
         k3[i] = (k1[i] * rs[i]) * dgn;
     }
-    for (int r = rl; r < rows; r += 128) {
-        float g[8];
-        unpack8(*(const uint4*)(dy + (size_t)r * c + col0), g);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (rl + 128 * k >= rows) continue;
+        float o[W][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float gk = win[k][i] >= 0 ? k1[i] * g[k][i] : 0.f;
+#pragma unroll
+            for (int q = 0; q < W; ++q)
+                o[q][i] = __builtin_fmaf(-k3[i], v[k][q][i], (win[k][i] == q ? gk : 0.f) - k2[i]);
+        }
+        uint16_t* p = dx + xoff[k];
+        *(uint4*)(p) = pack8(o[0]);
         if (POOL) {
-            float v[4][8], o[4][8];
-            const size_t ipix = geo.in_pixel((size_t)r);
-            load_window(x, ipix, cg, c, geo.hw, v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                bool live;
-                const int w = window_winner(__builtin_fmaf(v[0][i], ysc[i], ysh[i]),
-                                            __builtin_fmaf(v[1][i], ysc[i], ysh[i]),
-                                            __builtin_fmaf(v[2][i], ysc[i], ysh[i]),
-                                            __builtin_fmaf(v[3][i], ysc[i], ysh[i]), live);
-                const float gk = live ? k1[i] * g[i] : 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    o[q][i] = __builtin_fmaf(-k3[i], v[q][i], (w == q ? gk : 0.f) - k2[i]);
-            }
-            uint16_t* p = dx + ipix * c + col0;
-            *(uint4*)(p) = pack8(o[0]);
             *(uint4*)(p + c) = pack8(o[1]);
             *(uint4*)(p + (size_t)geo.hw * c) = pack8(o[2]);
             *(uint4*)(p + (size_t)geo.hw * c + c) = pack8(o[3]);
-        } else {
-            float v[8], o[8];
-            unpack8(*(const uint4*)(x + (size_t)r * c + col0), v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float gi = (__builtin_fmaf(v[i], ysc[i], ysh[i]) > 0.f) ? g[i] : 0.f;
-                o[i] = k1[i] * gi - k2[i] - k3[i] * v[i];
-            }
-            *(uint4*)(dx + (size_t)r * c + col0) = pack8(o);
         }
     }
 }
@@ -614,15 +610,9 @@ bool bn_relu_bwd_small(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const floa
     // (not for unsummed split slabs: 9 fp32 slabs are real bytes, 32 blocks cannot stream them)
     if (!use_slab_kernel(rows, c) || sl.splits > 0) return false;
     const PoolGeom none = {c / 8, 0, 0};
-    const float inv_n = 1.f / (float)rows;
-    if (sl.splits > 0)
-        hipLaunchKernelGGL((bn_bwd_slab_kernel<false, true>), dim3(c / 16), dim3(256), 0, stream, x,
-                           dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, rows, c, inv_n,
-                           none, sl);
-    else
-        hipLaunchKernelGGL((bn_bwd_slab_kernel<false, false>), dim3(c / 16), dim3(256), 0, stream, x,
-                           dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, rows, c, inv_n,
-                           none, sl);
+    hipLaunchKernelGGL(bn_bwd_slab_kernel<false>, dim3(c / 16), dim3(256), 0, stream, x,
+                       (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, rows,
+                       c, 1.f / (float)rows, none);
     return true;
 }
 
@@ -673,15 +663,9 @@ void bn_relu_pool_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float
     const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_bwd");
     const int out_rows = rows / 4;
     if (!sums.data && dx && sl.splits == 0 && use_slab_kernel(out_rows, c)) {
-        const float inv_n = 1.f / (float)rows;
-        if (sl.splits > 0)
-            hipLaunchKernelGGL((bn_bwd_slab_kernel<true, true>), dim3(c / 16), dim3(256), 0, stream, x,
-                               dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, out_rows, c,
-                               inv_n, geo, sl);
-        else
-            hipLaunchKernelGGL((bn_bwd_slab_kernel<true, false>), dim3(c / 16), dim3(256), 0, stream,
-                               x, dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, out_rows,
-                               c, inv_n, geo, sl);
+        hipLaunchKernelGGL(bn_bwd_slab_kernel<true>, dim3(c / 16), dim3(256), 0, stream, x,
+                           (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta,
+                           out_rows, c, 1.f / (float)rows, geo);
         return;
     }
     const ColReducePlan pl = plan_col_reduce(out_rows, c);

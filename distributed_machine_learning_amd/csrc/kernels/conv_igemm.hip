@@ -172,18 +172,34 @@ __device__ __forceinline__ void bn_pool_bwd_tile_sums(const f32x4 (&acc)[TN][TM]
         const int ox = m & (hw - 1), oy = (m >> p.log_hw) & (hw - 1);
         const size_t b = (size_t)(m >> (2 * p.log_hw));
         const uint16_t* win = p.bn_pre + (((b * in_hw + 2 * oy) * in_hw + 2 * ox) * p.N + nl);
+        // the lane's 4*TN consecutive channels at the four window positions, 16-byte loads
+        uint32_t wv[4][2 * TN];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint16_t* wk = win + ((k >> 1) ? (size_t)in_hw * p.N : 0) + ((k & 1) ? p.N : 0);
+            if constexpr (TN % 2 == 0) {
+#pragma unroll
+                for (int h = 0; h < TN / 2; ++h) {
+                    const uint4 t = *(const uint4*)(wk + 8 * h);
+                    wv[k][4 * h] = t.x; wv[k][4 * h + 1] = t.y;
+                    wv[k][4 * h + 2] = t.z; wv[k][4 * h + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const uint2 t = *(const uint2*)(wk + 4 * i);
+                    wv[k][2 * i] = t.x; wv[k][2 * i + 1] = t.y;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            const uint16_t* w0 = win + 4 * i;
-            const uint2 q[4] = {*(const uint2*)w0, *(const uint2*)(w0 + p.N),
-                                *(const uint2*)(w0 + (size_t)in_hw * p.N),
-                                *(const uint2*)(w0 + (size_t)in_hw * p.N + p.N)};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float best = 0.f, xw = 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t word = c < 2 ? q[k].x : q[k].y;
+                    const uint32_t word = wv[k][2 * i + (c >> 1)];
                     const float v =
                         bf16_bits_to_float((uint16_t)((c & 1) ? (word >> 16) : (word & 0xffff)));
                     const float z = __builtin_fmaf(v, ysc[i][c], ysh[i][c]);
