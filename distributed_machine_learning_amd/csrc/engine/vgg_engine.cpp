@@ -3,11 +3,15 @@
 // Schedule of one training step (reference order, /root/reference/part1/main.py:38-46):
 //   (nothing to zero: every gradient is overwritten)                optimizer.zero_grad()
 //   conv (+ BN statistics) -> [bn+relu(+pool)] | [pool] ...         model(data)
-//   classifier + softmax cross-entropy, forward and backward        criterion / backward
-//   then per conv layer back to front:
-//     [pool bwd] -> [bn+relu bwd] -> bias grad -> wgrad -> dgrad    loss.backward()
-//     -> partial-slab sums + reducer.bucket_ready(...) for every bucket this layer completes
-//   reducer.wait_all -> fused SGD -> weight shadow / repack          optimizer.step()
+//   classifier rows (logits, loss terms, dlogits, dx)               criterion / backward
+//   then per conv layer back to front, on the MAIN stream:
+//     [bn+relu(+pool) bwd | pool bwd] -> dgrad (+ the next layer's BatchNorm sums)
+//   and on the SIDE stream, handed over in groups of layers by one event each:
+//     classifier batch reductions, bias grad, wgrad, partial-slab sums,
+//     reducer.bucket_ready(...) for every bucket the group completes
+//   (the first layer's wgrad, which forms its gradient on the fly, and the last bucket stay on
+//   the main stream; without set_wgrad_overlap everything runs on the main stream)
+//   join -> reducer.wait_all -> fused SGD -> weight shadow / repack  optimizer.step()
 #include "dml_engine.h"
 
 #include <pybind11/pybind11.h>
@@ -271,8 +275,8 @@ void VggEngine::launch_wgrad(int i, int batch, hipStream_t stream) {
 // Side-stream mode: everything the main stream had produced when hand_off_[layer] was recorded
 // (the queued layers' gradients, the BatchNorm / classifier gradients of a departing bucket)
 // becomes visible to the side stream, which then runs the queued weight gradients and their sums.
-void VggEngine::hand_off_wgrads(int layer, int batch) {
-    (void)layer;        // the caller has ordered the side stream behind hand_off_[layer]
+void VggEngine::hand_off_wgrads(int batch) {
+    // (the caller has ordered the side stream behind the hand-off event)
     for (int i : wgrad_queue_) launch_wgrad(i, batch, wgrad_stream_);
     wgrad_queue_.clear();
     flush_wgrad_sums(wgrad_stream_);
@@ -549,7 +553,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                 fc_grads(wgrad_stream_);
                 fc_grads_pending = false;
             }
-            hand_off_wgrads(i, batch);
+            hand_off_wgrads(batch);
             for (int l : owed)
                 for (int b : buckets_by_layer_[l])
                     reducer_->bucket_ready(b, wgrad_stream_, bucket_update(b));

@@ -5,8 +5,9 @@
 // backward, step).  At MI355X speeds an iteration is about a millisecond, so the per-op
 // Python/autograd cost would dominate.  This engine instead walks a fixed layer plan in
 // C++ and enqueues every kernel of forward, loss, backward (with the bucket reducer's
-// hooks between layers) and the optimizer on one HIP stream; nothing in a step touches
-// the host allocator or synchronises, so a whole step can also be captured in a hipGraph.
+// hooks between layers) and the optimizer on the caller's HIP stream plus, for the weight
+// gradients, a side stream of its own; nothing in a step touches the host allocator or
+// synchronises, so a whole step can also be captured in a hipGraph.
 //
 // Memory is provided by the caller as six flat device buffers (so torch owns the
 // allocations and can view them as tensors):
@@ -14,7 +15,7 @@
 //                               weights stored [cout][3][3][cin] (KRSC), fc [10][512]
 //   bn_buffers                : fp32 running_mean / running_var slots
 //   arena                     : bf16 - weight shadows, dgrad-layout weights, activations,
-//                               gradient ping-pong buffers
+//                               one gradient buffer per layer + a transit buffer
 //   workspace                 : fp32 - logits, dlogits, loss / accuracy accumulators,
 //                               BatchNorm saved statistics, split-K slabs
 #pragma once
@@ -121,7 +122,7 @@ class VggEngine {
     void fire_buckets(int layer, hipStream_t stream);
     void flush_wgrad_sums(hipStream_t stream);
     void join_wgrad_stream(hipStream_t stream);
-    void hand_off_wgrads(int layer, int batch);
+    void hand_off_wgrads(int batch);
     void launch_wgrad(int layer, int batch, hipStream_t stream);
     size_t layer_begin(int layer) const;    // flat offset of the layer's first parameter slot
     void sgd_slice(size_t begin, size_t end, hipStream_t stream);
