@@ -579,7 +579,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             join_wgrad_stream(stream);      // usually fired long ago (recorded at the last hand-off)
             for (int l : owed)
                 for (int b : buckets_by_layer_[l])
-                    reducer_->bucket_ready(b, stream, bucket_update(b));
+                    reducer_->bucket_ready(b, stream, bucket_update(b), /*in_line=*/true);
             owed.clear();
         }
         if (!side) fire_buckets(i, stream);

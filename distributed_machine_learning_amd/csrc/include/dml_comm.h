@@ -128,8 +128,10 @@ class BucketReducer {
     void begin_step();
     // `after` (optional) is enqueued behind the bucket's all-reduce on the stream that ran it,
     // before the bucket counts as done - e.g. the optimizer update of the bucket's parameters
+    // `in_line`: run the all-reduce on `compute` itself instead of the communication stream
     void bucket_ready(int b, hipStream_t compute,
-                      const std::function<void(hipStream_t)>& after = nullptr);
+                      const std::function<void(hipStream_t)>& after = nullptr,
+                      bool in_line = false);
     void wait_all(hipStream_t compute);
     hipStream_t comm_stream() const { return comm_stream_; }
 
