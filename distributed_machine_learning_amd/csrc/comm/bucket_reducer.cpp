@@ -39,9 +39,10 @@ std::vector<BucketRange> plan_buckets(const std::vector<size_t>& sizes_bytes, si
 }
 
 namespace {
-// The events only order two streams of ONE device (the RCCL kernel that consumes a bucket
-// runs on this GPU and does its own cross-GPU fencing), so a device-scope release is enough.
-constexpr unsigned kEventFlags = hipEventDisableTiming | hipEventReleaseToDevice;
+// Default release scope on purpose (no hipEventReleaseToDevice): the "ready" event is what makes
+// the gradients this GPU's kernels just wrote visible beyond its own L2 - with more than one
+// rank, peers read a bucket straight out of this GPU's memory over xGMI.
+constexpr unsigned kEventFlags = hipEventDisableTiming;
 
 void check_hip(hipError_t e, const char* what) {
     if (e != hipSuccess)
