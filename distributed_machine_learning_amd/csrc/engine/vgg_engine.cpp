@@ -342,11 +342,17 @@ std::vector<std::vector<long long>> VggEngine::layer_table() const {
     return out;
 }
 
-void VggEngine::repack_all(hipStream_t stream) {
+void VggEngine::repack_all(hipStream_t stream, const float* copy_src, float* copy_dst,
+                           size_t copy_n) {
     // backward-data weight layout for every conv after the first, 16 layers per launch; the
     // first layer's padded bf16 layout rides in the first launch
     const float* c1 = params_ + convs_[0].w_off;
-    if (convs_.size() == 1) repack_conv1_weights(c1, arena_ + w1_off_, stream);
+    if (convs_.size() == 1) {
+        repack_conv1_weights(c1, arena_ + w1_off_, stream);
+        if (copy_n)
+            check_hip(hipMemcpyAsync(copy_dst, copy_src, copy_n * sizeof(float),
+                                     hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(buffers)");
+    }
     RepackJobs jobs;
     for (size_t i = 1; i < convs_.size(); ++i) {
         const Conv& c = convs_[i];
@@ -355,7 +361,8 @@ void VggEngine::repack_all(hipStream_t stream) {
         jobs.src_off[jobs.n] = shadow_off_ + c.w_off;
         jobs.dst_off[jobs.n] = c.wd_off;
         if (++jobs.n == RepackJobs::kMax || i + 1 == convs_.size()) {
-            repack_dgrad_weights_batch(arena_, arena_, jobs, stream, c1, arena_ + w1_off_);
+            repack_dgrad_weights_batch(arena_, arena_, jobs, stream, c1, arena_ + w1_off_, copy_src,
+                                       copy_dst, c1 ? copy_n : 0);
             c1 = nullptr;
             jobs.n = 0;
         }
@@ -464,6 +471,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     };
     bool fc_grads_pending = side;
     if (!side) fc_grads(stream);
+    bool stage_buffers_pending = side && reducer_ && bn_;
     // side mode: a completed bucket leaves (from the side stream) with the next hand-off
     std::vector<int> owed;          // layers whose buckets are complete but not yet sent off
     if (!side) fire_buckets(nconv, stream);
@@ -553,6 +561,10 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                 fc_grads(wgrad_stream_);
                 fc_grads_pending = false;
             }
+            if (stage_buffers_pending) {    // forward is over: rank 0's running statistics are final
+                reducer_->buffers_updated(wgrad_stream_);
+                stage_buffers_pending = false;
+            }
             hand_off_wgrads(batch);
             for (int l : owed)
                 for (int b : buckets_by_layer_[l])
@@ -574,6 +586,10 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
         if (i == 0 && fc_grads_pending) {    // a network with a single conv layer: no hand-off
             fc_grads(stream);
             fc_grads_pending = false;
+        }
+        if (i == 0 && stage_buffers_pending) {
+            reducer_->buffers_updated(stream);
+            stage_buffers_pending = false;
         }
         if (side && i == 0 && !owed.empty()) {
             join_wgrad_stream(stream);      // usually fired long ago (recorded at the last hand-off)
@@ -603,7 +619,9 @@ void VggEngine::forward_backward(const uint16_t* x, const int64_t* target, int b
         reducer_->apply_buffers(stream);        // running statistics := rank 0's
     }
     forward(x, batch, true, stream);
-    if (reducer_ && bn_) reducer_->buffers_updated(stream);
+    // (side-stream mode: the staging copy of the running statistics leaves the main chain and
+    // goes with the first hand-off, see backward)
+    if (reducer_ && bn_ && !wgrad_overlap_) reducer_->buffers_updated(stream);
     backward(x, target, batch, stream);
 }
 
@@ -619,7 +637,11 @@ void VggEngine::optimizer_step(float lr, float momentum, float weight_decay, flo
         sgd_momentum(params_, grads_, mom_, arena_ + shadow_off_, param_elems_, lr, momentum,
                      weight_decay, grad_scale, false, stream);
     }
-    repack_all(stream);
+    // the running statistics every rank adopts from rank 0 (see BucketReducer) arrived with the
+    // gradients: their copy into the live buffers rides in the repack launch
+    const float* bsrc = nullptr; float* bdst = nullptr; size_t bn = 0;
+    if (reducer_) (void)reducer_->take_pending_buffers(&bsrc, &bdst, &bn);
+    repack_all(stream, bsrc, bdst, bn);
 }
 
 void VggEngine::eval_step(const uint16_t* x, const int64_t* target, int batch, hipStream_t stream) {

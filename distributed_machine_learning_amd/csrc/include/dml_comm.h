@@ -139,6 +139,15 @@ class BucketReducer {
     void buffers_updated(hipStream_t compute);      // call after the forward pass
     void apply_buffers(hipStream_t compute);        // call before the next forward pass
     void drop_pending_buffers() { buffers_pending_ = buffers_staged_ = false; }
+    // After wait_all: hands the copy "staging -> live buffers" that apply_buffers would issue at
+    // the next step to the caller (who can let it ride in a launch it makes anyway); false if
+    // there is nothing to copy.
+    bool take_pending_buffers(const float** src, float** dst, size_t* count) {
+        if (!buffers_count_ || !buffers_pending_) return false;
+        buffers_pending_ = false;
+        *src = buffers_staging_; *dst = buffers_; *count = buffers_count_;
+        return true;
+    }
 
   private:
     RcclComm* comm_;

@@ -126,7 +126,8 @@ class VggEngine {
     void launch_wgrad(int layer, int batch, hipStream_t stream);
     size_t layer_begin(int layer) const;    // flat offset of the layer's first parameter slot
     void sgd_slice(size_t begin, size_t end, hipStream_t stream);
-    void repack_all(hipStream_t stream);
+    void repack_all(hipStream_t stream, const float* copy_src = nullptr, float* copy_dst = nullptr,
+                    size_t copy_n = 0);
 
     std::vector<Conv> convs_;
     int max_batch_, num_classes_, fc_in_;

@@ -140,7 +140,9 @@ struct RepackJobs {
 };
 void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, RepackJobs jobs,
                                 hipStream_t stream, const float* conv1_w = nullptr,
-                                bf16_raw* conv1_w1 = nullptr);
+                                bf16_raw* conv1_w1 = nullptr, const float* copy_src = nullptr,
+                                float* copy_dst = nullptr, size_t copy_n = 0);
+// (copy_*: a small fp32 device copy that rides in the same launch)
 // w1[64][64] bf16 (k = tap*4 + c) from master fp32 [64][9][3]
 void repack_conv1_weights(const float* w, bf16_raw* w1, hipStream_t stream);
 

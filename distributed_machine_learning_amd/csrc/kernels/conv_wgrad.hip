@@ -359,11 +359,20 @@ __global__ __launch_bounds__(256) void repack_dgrad_batch_kernel(const uint16_t*
                                                                  uint16_t* __restrict__ dst,
                                                                  RepackJobs jobs,
                                                                  const float* __restrict__ conv1_w,
-                                                                 uint16_t* __restrict__ conv1_w1) {
+                                                                 uint16_t* __restrict__ conv1_w1,
+                                                                 const float* __restrict__ copy_src,
+                                                                 float* __restrict__ copy_dst,
+                                                                 int copy_n) {
     __shared__ uint16_t tile[64][66];
     const int total = jobs.tile_start[jobs.n];
-    if ((int)blockIdx.x >= total) {         // the 16 trailing blocks: first-layer weight layout
-        repack_conv1_block(conv1_w, conv1_w1, blockIdx.x - total);
+    if ((int)blockIdx.x >= total) {
+        const int extra = blockIdx.x - total;
+        if (conv1_w && extra < 16) {        // 16 trailing blocks: first-layer weight layout
+            repack_conv1_block(conv1_w, conv1_w1, extra);
+        } else {                            // then: a small fp32 copy riding in this launch
+            const int i = (extra - (conv1_w ? 16 : 0)) * 256 + threadIdx.x;
+            if (i < copy_n) copy_dst[i] = copy_src[i];
+        }
         return;
     }
     int j = 0;
@@ -378,9 +387,13 @@ __global__ __launch_bounds__(256) void repack_dgrad_batch_kernel(const uint16_t*
 }
 
 void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, RepackJobs jobs,
-                                hipStream_t stream, const float* conv1_w, bf16_raw* conv1_w1) {
+                                hipStream_t stream, const float* conv1_w, bf16_raw* conv1_w1,
+                                const float* copy_src, float* copy_dst, size_t copy_n) {
     if (jobs.n <= 0) {
         if (conv1_w) repack_conv1_weights(conv1_w, conv1_w1, stream);
+        if (copy_n)
+            (void)hipMemcpyAsync(copy_dst, copy_src, copy_n * sizeof(float), hipMemcpyDeviceToDevice,
+                                 stream);
         return;
     }
     if (jobs.n > RepackJobs::kMax) throw std::invalid_argument("repack batch: too many layers");
@@ -392,8 +405,10 @@ void repack_dgrad_weights_batch(const bf16_raw* src_base, bf16_raw* dst_base, Re
         total += (jobs.cin[j] / 64) * (jobs.cout[j] / 64) * 9;
     }
     jobs.tile_start[jobs.n] = total;
-    hipLaunchKernelGGL(repack_dgrad_batch_kernel, dim3(total + (conv1_w ? 16 : 0)), dim3(256), 0,
-                       stream, src_base, dst_base, jobs, conv1_w, conv1_w1);
+    const int copy_blocks = (int)((copy_n + 255) / 256);
+    hipLaunchKernelGGL(repack_dgrad_batch_kernel, dim3(total + (conv1_w ? 16 : 0) + copy_blocks),
+                       dim3(256), 0, stream, src_base, dst_base, jobs, conv1_w, conv1_w1, copy_src,
+                       copy_dst, (int)copy_n);
 }
 
 __global__ __launch_bounds__(256) void repack_conv1_kernel(const float* __restrict__ w,
