@@ -123,6 +123,10 @@ def fun_main(cfg: TrainConfig):
             print(f"[rank {cfg.rank}] could not join the process group at {cfg.master_ip}: "
                   f"{exc}", file=sys.stderr)
             raise SystemExit(2)
+    if comm is not None and device.type == "cuda":
+        # collectives are enqueued on the compute stream in the two manual modes (and for the
+        # last bucket of the DDP mode): keep RCCL's kernels off the legacy null stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=device))
     # identical initial weights on every rank: seed after joining, before the model exists
     torch.manual_seed(cfg.seed)
     if comm is not None:
