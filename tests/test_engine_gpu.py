@@ -410,3 +410,30 @@ def test_cli_on_gpu_prints_reference_lines(capsys):
     assert "Average execution time is  :" in out
     assert "Test set: Average loss:" in out
     assert res["avg_s_per_iter"] > 0
+
+
+def test_bench_prints_one_json_record():
+    """bench.py's stdout is exactly one JSON line with the fields the harness reads - also when
+    a communicator (and with it RCCL's start-up banner) is in play."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for extra in ([], ["--force-comm"]):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5",
+                              "--warmup", "2"] + extra, capture_output=True, text=True, env=env,
+                             timeout=300, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, out.stdout
+        rec = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert key in rec, key
+        assert rec["n_gpus"] == 1 and rec["steps"] == 5 and rec["warmup"] == 2
+        assert rec["dtype"] == "bf16" and rec["data"] == "synthetic" and rec["scaling"] == "weak"
+        assert rec["value"] > 0 and rec["higher_is_better"] is True
+        assert abs(rec["value"] - rec["config"]["global_batch"] / (rec["ms_per_step"] / 1e3)) \
+            < 0.01 * rec["value"]
