@@ -10,7 +10,7 @@ of size R*B.
 from __future__ import annotations
 
 import math
-from typing import Iterator, List, Optional, Tuple
+from typing import Iterator, Optional, Tuple
 
 import torch
 

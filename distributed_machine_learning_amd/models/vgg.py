@@ -10,7 +10,7 @@ all walk one description of the network.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Union
+from typing import List, Optional
 
 import torch
 from torch import nn

@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import datetime
 import os
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 

@@ -16,7 +16,6 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
-from typing import Optional
 
 _roctx = None
 _roctx_tried = False
