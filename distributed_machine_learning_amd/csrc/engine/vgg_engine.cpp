@@ -183,7 +183,10 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         Conv& c = convs_[i];
         c.wslab_off = w;
         if (i == 0) continue;
-        const int splits = conv3x3_wgrad_splits({max_batch_, c.hw, c.cin, c.cout});
+        // (room for either block target, see wgrad_split_target())
+        const ConvShape ws_shape = {max_batch_, c.hw, c.cin, c.cout};
+        const int s_a = conv3x3_wgrad_splits(ws_shape, 0), s_b = conv3x3_wgrad_splits(ws_shape, 288);
+        const int splits = s_a > s_b ? s_a : s_b;
         if (splits > 1) w = align_up(w + (size_t)splits * c.cout * 9 * c.cin);
     }
     ws_elems_ = w;
@@ -260,8 +263,9 @@ void VggEngine::launch_wgrad(int i, int batch, hipStream_t stream) {
     // noise), so it is left at the zero the buffer was allocated with.  Without BatchNorm
     // nothing else in a backward pass touches the reduction scratch.
     if (!bn_) column_sum(g, grads_ + c.b_off, batch * c.hw * c.hw, c.cout, ws_ + stats_off_, stream);
-    conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream, 0, ws_ + c.wslab_off);
-    const int splits = conv3x3_wgrad_splits(s);
+    const int target = wgrad_split_target();
+    conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream, 0, ws_ + c.wslab_off, target);
+    const int splits = conv3x3_wgrad_splits(s, target);
     if (splits > 1) {       // partial results per split, summed by flush_wgrad_sums
         if (wgrad_sums_.n == SlabSumJobs::kMax) flush_wgrad_sums(stream);
         const int j = wgrad_sums_.n++;

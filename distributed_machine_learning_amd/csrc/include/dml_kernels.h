@@ -114,8 +114,9 @@ void conv1_wgrad_relu_pool(const bf16_raw* x, const bf16_raw* act, const bf16_ra
 // caller sums the conv3x3_wgrad_splits(s) partials (sum_slabs_batch); with a single split `dw`
 // is written directly.
 void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
-                   hipStream_t stream, int force_splits = 0 /* tuning */, float* slab = nullptr);
-int conv3x3_wgrad_splits(ConvShape s);
+                   hipStream_t stream, int force_splits = 0 /* tuning */, float* slab = nullptr,
+                   int split_target = 0 /* blocks to aim for, 0: the kernel's own optimum */);
+int conv3x3_wgrad_splits(ConvShape s, int split_target = 0);
 
 // dst[job][i] = sum_k src[job][k * count + i] for up to 32 jobs in one launch (offsets in
 // floats from the two bases, counts multiples of 4): the reduction behind the slab mode above.

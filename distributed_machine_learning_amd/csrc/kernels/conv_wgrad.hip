@@ -218,11 +218,14 @@ int ilog2w(int v) {
 // Pixel-range splits, keeping >= 4 K steps per block.  Measured optimum on MI355X (batch
 // 256, tools/bench_conv.py): with atomic accumulation ~1.1 blocks per CU (every further split
 // adds |dw| of atomic traffic); with per-split slabs, where a split only costs plain stores,
-// ~1.7 blocks per CU (432 blocks: two 80 KB-LDS blocks share most CUs).
+// ~1.7 blocks per CU (432 blocks: two 80 KB-LDS blocks share most CUs).  `split_target`
+// overrides the block target: when the kernel runs on a side stream next to a longer main
+// chain, fewer splits (less slab traffic competing with the main chain) serve the step better.
 struct SplitPlan { int splits, steps_per_split; };
-SplitPlan plan_splits(int M, int tiles, int force_splits, bool slab_mode = true) {
+SplitPlan plan_splits(int M, int tiles, int force_splits, bool slab_mode = true,
+                      int split_target = 0) {
     const int total_steps = (M + 63) / 64;
-    const int target = slab_mode ? 432 : 288;
+    const int target = split_target > 0 ? split_target : slab_mode ? 432 : 288;
     int splits = slab_mode ? (target + tiles / 2) / tiles : (target + tiles - 1) / tiles;
     // a short reduction under tiles that already cover half the chip (the 2x2 layers): the
     // partial slabs and their sum would cost more than the split saves
@@ -241,11 +244,12 @@ int wgrad_tiles(const ConvShape& s) {
 }
 
 template <int BCO, int BCI>
-void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab) {
+void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab,
+                  int split_target) {
     a.tiles_co = a.Cout / BCO;
     a.tiles_ci = a.Cin / BCI;
     const int tiles = a.tiles_co * a.tiles_ci * 9;
-    const SplitPlan sp = plan_splits(a.M, tiles, force_splits, slab != nullptr);
+    const SplitPlan sp = plan_splits(a.M, tiles, force_splits, slab != nullptr, split_target);
     a.steps_per_split = sp.steps_per_split;
     a.split_stride = 0;
     a.atomic = sp.splits > 1 ? 1 : 0;
@@ -267,12 +271,12 @@ void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab
 
 }  // namespace
 
-int conv3x3_wgrad_splits(ConvShape s) {
-    return plan_splits(s.batch * s.hw * s.hw, wgrad_tiles(s), 0, true).splits;
+int conv3x3_wgrad_splits(ConvShape s, int split_target) {
+    return plan_splits(s.batch * s.hw * s.hw, wgrad_tiles(s), 0, true, split_target).splits;
 }
 
 void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
-                   hipStream_t stream, int force_splits, float* slab) {
+                   hipStream_t stream, int force_splits, float* slab, int split_target) {
     if (s.batch <= 0 || s.hw < 1 || s.hw > 32 || (s.hw & (s.hw - 1)) || s.cin % 64 ||
         s.cout % 64 || s.cin < 64 || s.cout < 64)
         throw std::invalid_argument("conv3x3_wgrad: needs hw power of two <= 32, cin % 64 == 0, "
@@ -287,11 +291,11 @@ void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s
     a.x_bytes = (unsigned)((size_t)a.M * s.cin * 2);
     a.dy_bytes = (unsigned)((size_t)a.M * s.cout * 2);
     if (s.cout % 128 == 0) {
-        if (s.cin % 128 == 0) launch_wgrad<128, 128>(a, stream, force_splits, slab);
-        else launch_wgrad<128, 64>(a, stream, force_splits, slab);
+        if (s.cin % 128 == 0) launch_wgrad<128, 128>(a, stream, force_splits, slab, split_target);
+        else launch_wgrad<128, 64>(a, stream, force_splits, slab, split_target);
     } else {        // 64-channel layers of the deeper VGG variants (64 -> 64 at 32x32)
-        if (s.cin % 128 == 0) launch_wgrad<64, 128>(a, stream, force_splits, slab);
-        else launch_wgrad<64, 64>(a, stream, force_splits, slab);
+        if (s.cin % 128 == 0) launch_wgrad<64, 128>(a, stream, force_splits, slab, split_target);
+        else launch_wgrad<64, 64>(a, stream, force_splits, slab, split_target);
     }
 }
 
