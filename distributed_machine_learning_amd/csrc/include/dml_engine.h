@@ -122,7 +122,7 @@ class VggEngine {
     void fire_buckets(int layer, hipStream_t stream);
     void flush_wgrad_sums(hipStream_t stream);
     void join_wgrad_stream(hipStream_t stream);
-    void hand_off_wgrads(int batch);
+    void hand_off_wgrads(int batch, bool last);
     void launch_wgrad(int layer, int batch, hipStream_t stream);
     // Blocks the weight-gradient kernels aim for.  Under BatchNorm the main chain of the
     // two-stream backward is the longer one, and fewer splits (less slab traffic competing with
