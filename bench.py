@@ -1,41 +1,52 @@
 """Headline benchmark: VGG-11 training throughput on synthetic CIFAR-10-shaped data.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 8 --steps 200 --warmup 20          # starts its own 8 ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
 
 Flagship configuration = the reference's fastest variant (part3,
 /root/reference/part3/main.py): VGG-11 with BatchNorm, SGD lr 0.1 / momentum 0.9 /
-weight decay 1e-4, bucketed all-reduce (25 MB buckets, mean) overlapped with backward,
-here with 256 images per GPU (weak scaling), bf16 compute with fp32 master weights.
+weight decay 1e-4, bucketed all-reduce (mean) overlapped with backward, here with 256
+images per GPU (weak scaling), bf16 compute with fp32 master weights.
 The timed region is the reference's (/root/reference/part3/main.py:50-67): zero_grad,
 forward, loss, backward (+ gradient sync), optimizer step; batches are prepared before.
 Other reference configurations: ``--mode part1|part2a|part2b|part3`` and
 ``--no-batch-norm``; ``--backend torch`` times stock PyTorch-ROCm on the same GPU.
 
+Launching.  One process per GPU, like the reference's one process per node
+(/root/reference/part2/2a/main.py:194-218).  With ``--gpus N > 1`` and no launcher
+environment (RANK / WORLD_SIZE) this script starts the N ranks itself: the parent never
+touches the GPU, never replaces itself with another program, only spawns children, relays
+rank 0's record and enforces a deadline.  Under torchrun it is simply one of the ranks.
+
 Rank 0 prints ONE JSON line; ``value`` is whole-job images/sec, ``vs_baseline`` divides by
-the best number the reference publishes (part3 on its 4-node CPU cluster, 305.4 images/s).
+the number the reference publishes for the same mode (part3: 305.4 images/s on its 4-node
+CPU cluster).  Beyond the harness fields the record proves what ran: the rank count the
+transport itself reports (``rccl_nranks``), every rank's own step time, whether the
+parameters of all ranks are bit-identical after the timed loop (``params_in_sync``), the
+gradient bucket plan, the communication / compute split, and the min / median over further
+timing windows.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from distributed_machine_learning_amd.config import SEED, TrainConfig  # noqa: E402
 
 REFERENCE_IMAGES_PER_SEC = {"part1": 106.8, "part2a": 211.4, "part2b": 273.9, "part3": 305.4}
 MODE_SYNC = {"part1": "none", "part2a": "gather_scatter", "part2b": "all_reduce", "part3": "ddp"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -62,6 +73,11 @@ def parse():
                     help="split the last bucket so that at most this much completes with the "
                          "final wgrad ({conv4, conv3} then hide behind conv2/conv1 backward and "
                          "only {conv2, conv1}, 0.3 MB, is exposed)")
+    ap.add_argument("--grad-comm-dtype", choices=("fp32", "bf16"), default="fp32",
+                    help="part3: element type of the gradient buckets on the wire")
+    ap.add_argument("--inline-last-bucket", type=int, choices=(0, 1), default=None,
+                    help="part3: the bucket that ends backward on the compute stream (default: "
+                         "only with one rank)")
     ap.add_argument("--serialize-streams", action="store_true")
     ap.add_argument("--compute-stream", choices=("auto", "default", "new"), default="auto",
                     help="run the step on torch's default (null) stream or on a created one; auto: "
@@ -74,35 +90,122 @@ def parse():
     ap.add_argument("--fused-optimizer", type=int, default=0, choices=(0, 1),
                     help="SGD slices inside backward, behind each group's / bucket's gradients")
     ap.add_argument("--distinct-batches", type=int, default=4)
+    ap.add_argument("--windows", type=int, default=5,
+                    help="further timing windows of --steps steps after the measured one; their "
+                         "min / median go into the record's `windows` key")
     ap.add_argument("--report-overlap", action="store_true",
-                    help="with communication on: also time the step without collectives and the "
-                         "collectives alone, and report the exposed communication time and the "
-                         "overlap fraction (extra untimed steps after the measured region)")
+                    help="also with one rank (needs --force-comm): time the step without "
+                         "collectives and the collectives alone, and report the exposed "
+                         "communication time and the overlap fraction (extra untimed steps after "
+                         "the measured region).  Always on with more than one rank")
     ap.add_argument("--force-comm", action="store_true",
-                    help="build the RCCL communicator and sync strategy even with one rank")
-    return ap.parse_args()
+                    help="build the communicator and sync strategy even with one rank")
+    ap.add_argument("--transport", choices=("rccl", "loopback"), default="rccl",
+                    help="loopback: the TEST transport that lets several ranks share one GPU "
+                         "(RCCL refuses that); its numbers say nothing about xGMI")
+    ap.add_argument("--comm-timeout", type=float, default=120.0,
+                    help="deadline of every host-side wait on a collective")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="self-launch: kill all ranks and exit non-zero after this many seconds")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="self-launch check: every rank prints its launcher environment and "
+                         "exits without touching a GPU")
+    ap.add_argument("--profile-ranges", action="store_true",
+                    help="emit roctx ranges for the phases of the step (rocprofv3 --marker-trace)")
+    return ap.parse_args(argv)
 
 
-def main():
-    ns = parse()
+# ------------------------------------------------------------------------- self launch
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(ns, argv) -> int:
+    """Parent of a self-launched run.  Makes no GPU call and no exec of its own."""
+    port = _free_port()
+    procs = []
+    for rank in range(ns.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ns.gpus),
+                   LOCAL_WORLD_SIZE=str(ns.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DML_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), *argv],
+                                      env=env))
+    deadline = time.time() + ns.launch_timeout
+    code = 0
+    try:
+        alive = set(range(ns.gpus))
+        while alive:
+            for r in list(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0 and code == 0:
+                    code = rc
+                    print(f"[bench] rank {r} exited with code {rc}; stopping the others",
+                          file=sys.stderr)
+            if code != 0:
+                break
+            if time.time() > deadline:
+                print(f"[bench] ranks still running after {ns.launch_timeout:.0f} s; giving up",
+                      file=sys.stderr)
+                code = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        for p in procs:
+            try:
+                p.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return code
+
+
+# ------------------------------------------------------------------------------ a rank
+def run_rank(ns) -> None:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    master = f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{os.environ.get('MASTER_PORT', '29500')}"
+    if world != ns.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {ns.gpus}")
+    if ns.dry_launch:
+        # one write per line: the ranks share the parent's stdout
+        os.write(1, (json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank,
+                                 "world_size": world, "master": master,
+                                 "self_launched": os.environ.get("DML_BENCH_SELF_LAUNCHED") == "1"})
+                     + "\n").encode())
+        return
+
+    import torch
+    from distributed_machine_learning_amd.config import SEED, TrainConfig
+
     # stdout carries exactly one line, the JSON record; everything else a library prints there
     # (RCCL's version banner at its first collective) is sent to stderr
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != ns.gpus:
-        if world == 1 and ns.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
-                             "(one process per GPU)")
-        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {ns.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU")
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if ns.transport == "loopback":
+        dev_index = local_rank % n_dev
+    elif local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPUs are visible "
+                         "(RCCL needs one GPU per rank)")
+    else:
+        dev_index = local_rank
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
-    if ns.compute_stream == "new" or (ns.compute_stream == "auto" and (world > 1 or ns.force_comm)):
+    use_comm = world > 1 or ns.force_comm
+    if ns.compute_stream == "new" or (ns.compute_stream == "auto" and use_comm):
         torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
     from distributed_machine_learning_amd.data import synthetic_cifar
@@ -111,10 +214,11 @@ def main():
     from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
 
     batch_norm = ns.batch_norm if ns.batch_norm is not None else (ns.mode == "part3")
-    use_comm = world > 1 or ns.force_comm
     sync = MODE_SYNC[ns.mode] if use_comm else "none"
-    master = f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{os.environ.get('MASTER_PORT', '29500')}"
-    comm = RcclCommunicator(master, rank, world, local_rank, timeout_s=120) if use_comm else None
+    comm = None
+    if use_comm:
+        comm = RcclCommunicator(master, rank, world, dev_index, timeout_s=ns.comm_timeout,
+                                transport=ns.transport)
 
     cfg = TrainConfig(master_ip=master, rank=rank, num_nodes=world, sync=sync,
                       batch_size=ns.batch_size, batch_norm=batch_norm, dtype=ns.dtype,
@@ -123,13 +227,19 @@ def main():
                       first_bucket_cap_mb=(ns.first_bucket_cap_mb if ns.first_bucket_cap_mb
                                            is not None else ns.bucket_cap_mb),
                       tail_bucket_cap_mb=ns.tail_bucket_cap_mb,
-                      serialize_streams=ns.serialize_streams,
+                      grad_comm_dtype=ns.grad_comm_dtype,
+                      inline_last_bucket=(None if ns.inline_last_bucket is None
+                                          else bool(ns.inline_last_bucket)),
+                      serialize_streams=ns.serialize_streams, comm_timeout_s=ns.comm_timeout,
                       wgrad_overlap=bool(ns.wgrad_overlap), wgrad_group=ns.wgrad_group,
                       fused_optimizer=bool(ns.fused_optimizer),
                       summary=False, eval=False)
     torch.manual_seed(SEED)
     backend = make_backend(cfg, device, comm)
     backend.train_mode(True)
+    if ns.profile_ranges and backend.name == "native":
+        from distributed_machine_learning_amd.ops import native
+        native.lib().set_trace_ranges(True)
 
     # synthetic CIFAR-shaped batches, rank-strided like the reference's sampler, prepared
     # (augmented, normalised, laid out) before the clock starts
@@ -143,9 +253,19 @@ def main():
         batches.append((tf(imgs, idx).contiguous(), labels.contiguous()))
 
     def barrier():
+        # bounded: a lost rank raises here instead of hanging the survivors
         if comm is not None:
-            comm.barrier()
+            comm.barrier(ns.comm_timeout)
         torch.cuda.synchronize()
+
+    def timed(n, first=0):
+        barrier()
+        t = time.perf_counter()
+        last = None
+        for i in range(n):
+            last = backend.train_step(*batches[(first + i) % len(batches)])
+        barrier()
+        return time.perf_counter() - t, last
 
     # RCCL builds its channels on first use of each collective: do that outside any timed or
     # counted step (the gradient buffer is still all zeros here)
@@ -157,59 +277,91 @@ def main():
     loss = None
     for i in range(ns.warmup):
         loss = backend.train_step(*batches[i % len(batches)])
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(ns.steps):
-        loss = backend.train_step(*batches[i % len(batches)])
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, last = timed(ns.steps)             # THE measured region: exactly --steps steps
+    loss = last if last is not None else loss
+    final_loss = float(loss.item()) if loss is not None else float("nan")
 
-    # outside the timed region: host cost of enqueueing a step into an empty queue
-    probe = 4
+    # ---- everything below is outside the measured region
+    windows = [timed(ns.steps)[0] for _ in range(max(ns.windows, 0))]
+    probe = 4                                   # host cost of enqueueing a step into an empty queue
     t1 = time.perf_counter()
     for i in range(probe):
         backend.train_step(*batches[i % len(batches)])
     host_elapsed = time.perf_counter() - t1
     barrier()
 
+    # ---- cross-rank self checks
+    per_rank_ms = [elapsed / ns.steps * 1e3]
+    nranks_seen = 1
+    in_sync = None
+    if comm is not None:
+        nranks_seen = comm.peer_count
+        times = comm.all_gather_scalars(elapsed, torch.float32)
+        per_rank_ms = [round(float(t) / ns.steps * 1e3, 4) for t in times]
+        elapsed = float(times.max())                        # MAX over ranks
+        if windows:
+            w = torch.zeros(world, len(windows), device=device)
+            w[rank] = torch.tensor(windows, device=device)
+            comm.all_reduce(w)
+            comm.guard_sync(ns.comm_timeout)
+            windows = [float(v) for v in w.max(dim=0).values.cpu()]
+        # bit pattern checksum of the master weights: equal on every rank, or training diverged
+        flat = backend.parameters_flat()
+        checksum = int(flat.view(torch.int32).to(torch.int64).sum().item())
+        sums = comm.all_gather_scalars(checksum, torch.int64)
+        in_sync = bool((sums == sums[0]).all())
+
     overlap = None
-    if ns.report_overlap and comm is not None:
+    if comm is not None and (world > 1 or ns.report_overlap):
         from distributed_machine_learning_amd.utils.overlap import measure_comm_split
         overlap = measure_comm_split(backend, comm, batches, n=max(10, min(ns.steps, 50)))
-
-    if comm is not None:       # MAX over ranks
-        times = torch.zeros(world, device=device)
-        times[rank] = elapsed
-        comm.all_reduce(times, "sum")
-        torch.cuda.synchronize()
-        elapsed = float(times.max())
-    final_loss = float(loss.item()) if loss is not None else float("nan")
 
     if rank == 0:
         ms = elapsed / ns.steps * 1e3
         value = ns.batch_size * world * ns.steps / elapsed
         par = "single" if world == 1 else f"dp{world}"
-        record = json.dumps({
+        win_ms = sorted(w / ns.steps * 1e3 for w in windows)
+        record = {
             "metric": "images/sec, VGG-11 CIFAR-10-shaped training, batch 256 per GPU",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": ns.steps,
             "warmup": ns.warmup, "ms_per_step": round(ms, 4), "s_per_iter": round(ms / 1e3, 7),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(value / REFERENCE_IMAGES_PER_SEC["part3"], 2),
+            "vs_baseline": round(value / REFERENCE_IMAGES_PER_SEC[ns.mode], 2),
             "dtype": ns.dtype, "data": "synthetic",
+            "rccl_nranks": nranks_seen, "transport": ns.transport if comm is not None else "none",
+            "per_rank_ms_per_step": per_rank_ms, "params_in_sync": in_sync,
+            "windows": ({"n": len(win_ms), "steps_each": ns.steps,
+                         "min_ms_per_step": round(win_ms[0], 4),
+                         "median_ms_per_step": round(win_ms[len(win_ms) // 2], 4),
+                         "max_ms_per_step": round(win_ms[-1], 4)} if win_ms else None),
             "config": {"model": "VGG-11" + (" + BatchNorm" if batch_norm else ""),
                        "mode": ns.mode, "sync": sync, "global_batch": ns.batch_size * world,
                        "batch_per_gpu": ns.batch_size, "image": "3x32x32", "parallelism": par,
                        "optimizer": "SGD lr0.1 m0.9 wd1e-4 (fused)", "backend": backend.name,
-                       "graph": bool(ns.graph), "bucket_cap_mb": ns.bucket_cap_mb, "tail_bucket_cap_mb": ns.tail_bucket_cap_mb,
+                       "graph": bool(ns.graph), "bucket_cap_mb": ns.bucket_cap_mb,
+                       "tail_bucket_cap_mb": ns.tail_bucket_cap_mb,
+                       "sync_plan": backend.sync_plan() if hasattr(backend, "sync_plan") else None,
                        "host_enqueue_ms_per_step": round(host_elapsed / probe * 1e3, 4),
                        "final_loss": round(final_loss, 4), "overlap": overlap,
-                       "baseline": "reference part3: 305.4 images/s on 4 CPU nodes "
-                                   "(group25.pdf p7); part1: 106.8 images/s"}})
-        print(record, file=json_out, flush=True)
+                       "baseline": f"reference {ns.mode}: {REFERENCE_IMAGES_PER_SEC[ns.mode]} "
+                                   "images/s on its CPU cluster (group25.pdf)"}}
+        print(json.dumps(record), file=json_out, flush=True)
     backend.close()
     if comm is not None:
         comm.destroy()
+    if in_sync is False:
+        raise SystemExit("parameters differ between ranks after the timed loop")
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    ns = parse(argv)
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if ns.gpus > 1 and not launched:
+        return self_launch(ns, argv)
+    run_rank(ns)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

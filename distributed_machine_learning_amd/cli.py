@@ -69,6 +69,12 @@ def build_parser(defaults: TrainConfig, distributed_flags: bool = True) -> argpa
     p.add_argument("--serialize-streams", action="store_true",
                    default=defaults.serialize_streams,
                    help="debug: issue collectives on the compute stream (no overlap)")
+    p.add_argument("--grad-comm-dtype", choices=("fp32", "bf16"), default=defaults.grad_comm_dtype,
+                   help="ddp mode: element type of the gradient buckets on the wire")
+    p.add_argument("--inline-last-bucket", dest="inline_last_bucket", type=int, choices=(0, 1),
+                   default=defaults.inline_last_bucket,
+                   help="ddp mode: all-reduce the bucket that ends backward on the compute stream "
+                        "(default: only with one rank)")
     p.add_argument("--no-broadcast-buffers", dest="broadcast_buffers", action="store_false",
                    default=defaults.broadcast_buffers)
     p.add_argument("--comm-timeout", dest="comm_timeout_s", type=float,
@@ -114,15 +120,20 @@ def fun_main(cfg: TrainConfig):
     if device.type == "cuda":
         torch.cuda.set_device(device)
     comm = None
+    solo_cpu = False
     if cfg.sync != SYNC_NONE:
         print(f"master_ip = {cfg.master_ip} and nodes = {cfg.num_nodes}")
-        try:
-            comm = init_communicator(cfg.master_ip, cfg.rank, cfg.num_nodes, device,
-                                     cfg.comm_timeout_s)
-        except Exception as exc:     # rendezvous failure: clean message, non-zero exit
-            print(f"[rank {cfg.rank}] could not join the process group at {cfg.master_ip}: "
-                  f"{exc}", file=sys.stderr)
-            raise SystemExit(2)
+        # a group of one on the CPU device needs no transport (every strategy is the identity);
+        # with more ranks the CPU device has none to offer and init_communicator says so
+        solo_cpu = device.type != "cuda" and cfg.num_nodes == 1
+        if not solo_cpu:
+            try:
+                comm = init_communicator(cfg.master_ip, cfg.rank, cfg.num_nodes, device,
+                                         cfg.comm_timeout_s)
+            except Exception as exc:     # rendezvous failure: clean message, non-zero exit
+                print(f"[rank {cfg.rank}] could not join the process group at {cfg.master_ip}: "
+                      f"{exc}", file=sys.stderr)
+                raise SystemExit(2)
     if comm is not None and device.type == "cuda":
         # collectives are enqueued on the compute stream in the two manual modes (and for the
         # last bucket of the DDP mode): keep RCCL's kernels off the legacy null stream
@@ -132,7 +143,11 @@ def fun_main(cfg: TrainConfig):
     if comm is not None:
         print(f"[{os.getpid()}] world_size = {comm.world_size}, "
               + f"rank = {comm.rank}, backend={comm.backend}")
+    elif solo_cpu:
+        print(f"[{os.getpid()}] world_size = 1, rank = 0, backend=none")
     trainer = Trainer(cfg, device, comm)
+    # which engine and which precision actually run (the reference is fp32 on the CPU)
+    print(f"Engine: backend={trainer.backend.name}, dtype={trainer.cfg.dtype}, device={device}")
     try:
         result = trainer.run()
     finally:

@@ -41,6 +41,8 @@ class TrainConfig:
     broadcast_buffers: bool = True         # DDP default relied on by part3
     comm_timeout_s: float = 300.0
     serialize_streams: bool = False        # debug: run comm on the compute stream
+    grad_comm_dtype: str = "fp32"          # DDP bucket payload on the wire: "fp32" | "bf16"
+    inline_last_bucket: Optional[bool] = None   # None: on the compute stream only with one rank
 
     # --- model ---
     arch: str = "VGG11"

@@ -50,7 +50,7 @@ void check_hip(hipError_t e, const char* what) {
 }
 }  // namespace
 
-BucketReducer::BucketReducer(RcclComm* comm, float* flat_grads, std::vector<Slice> slices,
+BucketReducer::BucketReducer(Comm* comm, float* flat_grads, std::vector<Slice> slices,
                              bool average, bool serialize, hipStream_t compute_stream)
     : comm_(comm), grads_(flat_grads), slices_(std::move(slices)), average_(average),
       serialize_(serialize) {
@@ -85,21 +85,51 @@ void BucketReducer::bucket_ready(int b, hipStream_t compute,
     if (b < 0 || b >= (int)slices_.size()) throw std::out_of_range("BucketReducer: bucket index");
     if (launched_[b]) throw std::logic_error("BucketReducer: bucket marked ready twice");
     launched_[b] = 1;
-    const Slice& s = slices_[b];
     // in_line: the bucket that completes with the end of backward has nothing left to overlap
-    // with; run on the compute stream itself it skips two cross-queue hand-offs (~20 us).  RCCL
-    // orders it behind the collectives still running on the communication stream.
-    if (serialize_ || in_line) {       // same stream, no events
-        comm_->all_reduce(grads_ + s.offset, s.count, DT_F32, average_, compute);
+    // with; run on the compute stream itself it skips two cross-queue hand-offs (~20 us).  The
+    // transport orders it behind the collectives still running on the communication stream
+    // (one communicator serves its launches in issue order).
+    if (serialize_ || (in_line && inline_last_)) {       // same stream, no events
+        reduce_slice(b, compute);
         if (after) after(compute);
         return;
     }
     last_ready_ = b;
     check_hip(hipEventRecord(ready_[b], compute), "hipEventRecord(ready)");
     check_hip(hipStreamWaitEvent(comm_stream_, ready_[b], 0), "hipStreamWaitEvent(comm)");
-    comm_->all_reduce(grads_ + s.offset, s.count, DT_F32, average_, comm_stream_);
+    reduce_slice(b, comm_stream_);
     if (after) after(comm_stream_);
     check_hip(hipEventRecord(done_[b], comm_stream_), "hipEventRecord(done)");
+}
+
+void BucketReducer::set_bf16_payload(bf16_raw* wire) {
+    if (wire && average_)
+        throw std::invalid_argument("BucketReducer: the bf16 payload is summed; fold the mean "
+                                    "into the optimizer's gradient scale");
+    wire_ = wire;
+}
+
+void BucketReducer::reduce_slice(int b, hipStream_t stream) {
+    const Slice& s = slices_[b];
+    float* base = grads_ + s.offset;
+    if (!wire_) {
+        comm_->all_reduce(base, s.count, DT_F32, average_, stream);
+        return;
+    }
+    // bf16 on the wire: half the bytes per link.  Gradients are rounded once before the sum
+    // (the sum itself is formed by the transport in bf16), widened again behind it; the
+    // BatchNorm statistics a bucket may carry at its end stay fp32 in the same launch.
+    size_t n = s.count, tail = 0;
+    if (buffers_count_ && buffers_staging_ >= base && buffers_staging_ < base + s.count) {
+        n = (size_t)(buffers_staging_ - base);
+        tail = s.count - n;
+    }
+    cast_f32_to_bf16(base, wire_ + s.offset, n, stream);
+    comm_->group_start();
+    comm_->all_reduce(wire_ + s.offset, n, DT_BF16, false, stream);
+    if (tail) comm_->all_reduce(base + n, tail, DT_F32, false, stream);
+    comm_->group_end();
+    cast_bf16_to_f32(wire_ + s.offset, base, n, stream);
 }
 
 void BucketReducer::wait_all(hipStream_t compute) {
@@ -188,39 +218,70 @@ void bind_comm(py::module_& m) {
 
     m.def("rccl_unique_id", []() { return py::bytes(RcclComm::unique_id()); });
 
-    py::class_<RcclComm>(m, "RcclComm")
-        .def(py::init([](py::bytes uid, int rank, int world, int device) {
-            std::string id = uid;
-            py::gil_scoped_release rel;
-            return new RcclComm(id, rank, world, device);
-        }))
-        .def_property_readonly("rank", &RcclComm::rank)
-        .def_property_readonly("world_size", &RcclComm::world_size)
-        .def("all_reduce", [](RcclComm& c, uintptr_t buf, size_t n, int dt, bool avg, uintptr_t s) {
+    py::class_<Comm>(m, "Comm")
+        .def_property_readonly("rank", &Comm::rank)
+        .def_property_readonly("world_size", &Comm::world_size)
+        .def_property_readonly("transport", [](Comm& c) { return std::string(c.transport()); })
+        .def_property_readonly("peer_count", &Comm::peer_count)
+        .def("all_reduce", [](Comm& c, uintptr_t buf, size_t n, int dt, bool avg, uintptr_t s) {
             c.all_reduce((void*)buf, n, (DType)dt, avg, (hipStream_t)s);
         })
-        .def("broadcast", [](RcclComm& c, uintptr_t buf, size_t n, int dt, int root, uintptr_t s) {
+        .def("broadcast", [](Comm& c, uintptr_t buf, size_t n, int dt, int root, uintptr_t s) {
             c.broadcast((void*)buf, n, (DType)dt, root, (hipStream_t)s);
         })
-        .def("gather", [](RcclComm& c, uintptr_t send, std::vector<uintptr_t> recv, size_t n,
+        .def("gather", [](Comm& c, uintptr_t send, std::vector<uintptr_t> recv, size_t n,
                           int dt, int root, uintptr_t s) {
             std::vector<void*> r;
             for (auto p : recv) r.push_back((void*)p);
             c.gather((const void*)send, r, n, (DType)dt, root, (hipStream_t)s);
         })
-        .def("scatter", [](RcclComm& c, uintptr_t out, std::vector<uintptr_t> chunks, size_t n,
+        .def("scatter", [](Comm& c, uintptr_t out, std::vector<uintptr_t> chunks, size_t n,
                            int dt, int root, uintptr_t s) {
             std::vector<const void*> r;
             for (auto p : chunks) r.push_back((const void*)p);
             c.scatter((void*)out, r, n, (DType)dt, root, (hipStream_t)s);
         })
-        .def("group_start", &RcclComm::group_start)
-        .def("group_end", &RcclComm::group_end)
-        .def("wait_stream", [](RcclComm& c, uintptr_t s, double t) {
+        .def("group_start", &Comm::group_start)
+        .def("group_end", &Comm::group_end)
+        .def("wait_stream", [](Comm& c, uintptr_t s, double t) {
             py::gil_scoped_release rel;
             c.wait_stream((hipStream_t)s, t);
         })
-        .def("destroy", &RcclComm::destroy);
+        .def("destroy", [](Comm& c) {
+            py::gil_scoped_release rel;
+            c.destroy();
+        });
+
+    py::class_<RcclComm, Comm>(m, "RcclComm")
+        .def(py::init([](py::bytes uid, int rank, int world, int device) {
+            std::string id = uid;
+            py::gil_scoped_release rel;
+            return new RcclComm(id, rank, world, device);
+        }));
+
+    py::class_<LoopbackComm, Comm>(m, "LoopbackComm")
+        .def(py::init([](const std::string& name, int rank, int world, int device, double timeout) {
+            py::gil_scoped_release rel;
+            return new LoopbackComm(name, rank, world, device, timeout);
+        }));
+
+    py::class_<ManualSync>(m, "ManualSync")
+        .def(py::init([](Comm* comm, int mode, uintptr_t grads,
+                         std::vector<std::pair<size_t, size_t>> tensors, int root,
+                         uintptr_t slabs, size_t stride) {
+            std::vector<ManualSync::Slice> t;
+            for (auto& p : tensors) t.push_back({p.first, p.second});
+            return new ManualSync(comm, (ManualSync::Mode)mode, (float*)grads, t, root,
+                                  (float*)slabs, stride);
+        }), py::arg("comm"), py::arg("mode"), py::arg("grads"), py::arg("tensors"),
+            py::arg("root") = 0, py::arg("slabs") = 0, py::arg("stride") = 0,
+            py::keep_alive<1, 2>())
+        .def("run", [](ManualSync& m, uintptr_t s) { m.run((hipStream_t)s); })
+        .def_static("packed_elems", [](std::vector<std::pair<size_t, size_t>> tensors) {
+            std::vector<ManualSync::Slice> t;
+            for (auto& p : tensors) t.push_back({p.first, p.second});
+            return ManualSync::packed_elems(t);
+        });
 
     m.def("plan_buckets", [](std::vector<size_t> sizes, size_t cap, size_t first_cap) {
         std::vector<std::pair<int, int>> out;
@@ -229,7 +290,7 @@ void bind_comm(py::module_& m) {
     });
 
     py::class_<BucketReducer>(m, "BucketReducer")
-        .def(py::init([](RcclComm* comm, uintptr_t grads,
+        .def(py::init([](Comm* comm, uintptr_t grads,
                          std::vector<std::pair<size_t, size_t>> slices, bool average,
                          bool serialize, uintptr_t compute_stream) {
             std::vector<BucketReducer::Slice> s;
@@ -252,6 +313,10 @@ void bind_comm(py::module_& m) {
         })
         .def("apply_buffers", [](BucketReducer& r, uintptr_t s) { r.apply_buffers((hipStream_t)s); })
         .def("drop_pending_buffers", &BucketReducer::drop_pending_buffers)
+        .def("set_bf16_payload", [](BucketReducer& r, uintptr_t wire) {
+            r.set_bf16_payload((bf16_raw*)wire);
+        })
+        .def_property("inline_last", &BucketReducer::inline_last, &BucketReducer::set_inline_last)
         .def_property_readonly("comm_stream",
                                [](BucketReducer& r) { return (uintptr_t)r.comm_stream(); });
 }

@@ -39,17 +39,17 @@ ncclDataType_t nccl_type(DType dt) {
     throw std::invalid_argument("unknown dtype code");
 }
 
-size_t type_bytes(DType dt) {
+}  // namespace
+
+size_t dtype_bytes(DType dt) {
     switch (dt) {
         case DT_F32: return 4;
         case DT_BF16: return 2;
         case DT_I64: return 8;
         case DT_U8: return 1;
     }
-    return 0;
+    throw std::invalid_argument("unknown dtype code");
 }
-
-}  // namespace
 
 std::string RcclComm::unique_id() {
     ncclUniqueId id;
@@ -58,7 +58,7 @@ std::string RcclComm::unique_id() {
 }
 
 RcclComm::RcclComm(const std::string& unique_id, int rank, int world_size, int device)
-    : rank_(rank), world_(world_size), device_(device) {
+    : Comm(rank, world_size), device_(device) {
     if (unique_id.size() != sizeof(ncclUniqueId))
         throw std::invalid_argument("RcclComm: unique id must be " +
                                     std::to_string(sizeof(ncclUniqueId)) + " bytes");
@@ -85,6 +85,13 @@ void RcclComm::destroy() {
     }
 }
 
+int RcclComm::peer_count() {
+    int n = -1;
+    if (!comm_) throw std::logic_error("RcclComm: communicator destroyed");
+    check_nccl(ncclCommCount((ncclComm_t)comm_, &n), "ncclCommCount");
+    return n;
+}
+
 void RcclComm::group_start() {
     check_nccl(ncclGroupStart(), "ncclGroupStart");
     ++group_depth_;
@@ -94,6 +101,14 @@ void RcclComm::group_end() {
     if (group_depth_ <= 0) throw std::logic_error("RcclComm: group_end without group_start");
     --group_depth_;
     check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+    if (group_depth_ == 0) {
+        // the grouped transfers are enqueued now; the root's own copies follow them in stream
+        // order (they touch buffers no transfer of the group reads or writes)
+        for (const SelfCopy& c : deferred_copies_)
+            check_hip(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, c.stream),
+                      "hipMemcpyAsync(self copy)");
+        deferred_copies_.clear();
+    }
 }
 
 void RcclComm::all_reduce(void* buf, size_t count, DType dt, bool average, hipStream_t stream) {
@@ -101,12 +116,6 @@ void RcclComm::all_reduce(void* buf, size_t count, DType dt, bool average, hipSt
     check_nccl(ncclAllReduce(buf, buf, count, nccl_type(dt), average ? ncclAvg : ncclSum,
                              (ncclComm_t)comm_, stream),
                "ncclAllReduce");
-}
-
-void RcclComm::broadcast(void* buf, size_t count, DType dt, int root, hipStream_t stream) {
-    if (count == 0) return;
-    check_nccl(ncclBroadcast(buf, buf, count, nccl_type(dt), root, (ncclComm_t)comm_, stream),
-               "ncclBroadcast");
 }
 
 void RcclComm::broadcast(const void* send, void* recv, size_t count, DType dt, int root,
@@ -123,15 +132,13 @@ void RcclComm::gather(const void* send, const std::vector<void*>& recv, size_t c
     if (rank_ == root) {
         if ((int)recv.size() != world_)
             throw std::invalid_argument("RcclComm::gather: root needs world_size receive slabs");
-        if (recv[root] != send)
-            check_hip(hipMemcpyAsync(recv[root], send, count * type_bytes(dt),
-                                     hipMemcpyDeviceToDevice, stream),
-                      "hipMemcpyAsync(gather self)");
-        check_nccl(ncclGroupStart(), "ncclGroupStart");
+        group_start();
         for (int r = 0; r < world_; ++r)
             if (r != root)
                 check_nccl(ncclRecv(recv[r], count, t, r, (ncclComm_t)comm_, stream), "ncclRecv");
-        check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+        if (recv[root] != send)
+            deferred_copies_.push_back({recv[root], send, count * dtype_bytes(dt), stream});
+        group_end();
     } else {
         check_nccl(ncclSend(send, count, t, root, (ncclComm_t)comm_, stream), "ncclSend");
     }
@@ -144,15 +151,13 @@ void RcclComm::scatter(void* out, const std::vector<const void*>& chunks, size_t
     if (rank_ == root) {
         if ((int)chunks.size() != world_)
             throw std::invalid_argument("RcclComm::scatter: root needs world_size chunks");
-        check_nccl(ncclGroupStart(), "ncclGroupStart");
+        group_start();
         for (int r = 0; r < world_; ++r)
             if (r != root)
                 check_nccl(ncclSend(chunks[r], count, t, r, (ncclComm_t)comm_, stream), "ncclSend");
-        check_nccl(ncclGroupEnd(), "ncclGroupEnd");
         if (chunks[root] != out)
-            check_hip(hipMemcpyAsync(out, chunks[root], count * type_bytes(dt),
-                                     hipMemcpyDeviceToDevice, stream),
-                      "hipMemcpyAsync(scatter self)");
+            deferred_copies_.push_back({out, chunks[root], count * dtype_bytes(dt), stream});
+        group_end();
     } else {
         check_nccl(ncclRecv(out, count, t, root, (ncclComm_t)comm_, stream), "ncclRecv");
     }

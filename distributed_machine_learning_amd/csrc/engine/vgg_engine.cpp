@@ -21,6 +21,7 @@
 #include <stdexcept>
 
 #include "dml_kernels.h"
+#include "dml_trace.h"
 
 namespace py = pybind11;
 
@@ -281,6 +282,7 @@ void VggEngine::launch_wgrad(int i, int batch, hipStream_t stream) {
 // becomes visible to the side stream, which then runs the queued weight gradients and their sums.
 void VggEngine::hand_off_wgrads(int batch, bool last) {
     // (the caller has ordered the side stream behind the hand-off event)
+    TraceRange range("backward/wgrad-side");
     for (int i : wgrad_queue_) launch_wgrad(i, batch, wgrad_stream_);
     wgrad_queue_.clear();
     // The slab sums follow their weight gradients at once when a bucket may be waiting for them,
@@ -317,6 +319,7 @@ void VggEngine::set_reducer(BucketReducer* reducer, const std::vector<BucketRang
 
 void VggEngine::fire_buckets(int layer, hipStream_t stream) {
     if (!reducer_ || buckets_by_layer_[layer].empty()) return;
+    TraceRange range("backward/buckets");
     flush_wgrad_sums(stream);       // a bucket leaves with complete gradients
     for (int b : buckets_by_layer_[layer]) reducer_->bucket_ready(b, stream);
 }
@@ -379,6 +382,7 @@ void VggEngine::repack_all(hipStream_t stream, const float* copy_src, float* cop
 void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t stream) {
     if (!params_) throw std::logic_error("VggEngine: bind() first");
     if (batch <= 0 || batch > max_batch_) throw std::invalid_argument("VggEngine: bad batch size");
+    TraceRange range(training ? "forward" : "forward(eval)");
     const uint16_t* in = x;
     float* slab = ws_ + slab_off_;
     for (size_t i = 0; i < convs_.size(); ++i) {
@@ -441,6 +445,7 @@ void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t
 }
 
 void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hipStream_t stream) {
+    TraceRange range("backward");
     const int nconv = (int)convs_.size();
     float* slab = ws_ + slab_off_;
     const Conv& last = convs_[nconv - 1];
@@ -573,10 +578,13 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                 stage_buffers_pending = false;
             }
             hand_off_wgrads(batch, i <= 1);
-            for (int l : owed)
-                for (int b : buckets_by_layer_[l])
-                    reducer_->bucket_ready(b, wgrad_stream_, bucket_update(b));
-            owed.clear();
+            if (!owed.empty()) {
+                TraceRange buckets("backward/buckets");
+                for (int l : owed)
+                    for (int b : buckets_by_layer_[l])
+                        reducer_->bucket_ready(b, wgrad_stream_, bucket_update(b));
+                owed.clear();
+            }
             if (fuse_opt && !reducer_ && i <= 1) {
                 // The side stream's last hand-off: behind its sums the gradients of every layer
                 // but the first are final, and it would idle while the main stream finishes
@@ -600,6 +608,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
         }
         if (side && i == 0 && !owed.empty()) {
             join_wgrad_stream(stream);      // usually fired long ago (recorded at the last hand-off)
+            TraceRange buckets("backward/buckets(last)");
             for (int l : owed)
                 for (int b : buckets_by_layer_[l])
                     reducer_->bucket_ready(b, stream, bucket_update(b), /*in_line=*/true);
@@ -634,6 +643,7 @@ void VggEngine::forward_backward(const uint16_t* x, const int64_t* target, int b
 
 void VggEngine::optimizer_step(float lr, float momentum, float weight_decay, float grad_scale,
                                hipStream_t stream) {
+    TraceRange range("optimizer");
     if (reducer_) reducer_->wait_all(stream);
     if (opt_applied_) {
         if (lr != opt_.lr || momentum != opt_.mu || weight_decay != opt_.wd || grad_scale != opt_.gscale)
@@ -649,6 +659,21 @@ void VggEngine::optimizer_step(float lr, float momentum, float weight_decay, flo
     const float* bsrc = nullptr; float* bdst = nullptr; size_t bn = 0;
     if (reducer_) (void)reducer_->take_pending_buffers(&bsrc, &bdst, &bn);
     repack_all(stream, bsrc, bdst, bn);
+}
+
+void VggEngine::train_step(const uint16_t* x, const int64_t* target, int batch, float lr,
+                           float momentum, float weight_decay, float grad_scale,
+                           hipStream_t stream) {
+    TraceRange range("train_step");
+    forward_backward(x, target, batch, stream);
+    if (manual_sync_) {
+        // the two hand-written modes synchronise between backward and the update
+        // (/root/reference/part2/2a/main.py:63, part2/2b/main.py:60)
+        TraceRange sync(manual_sync_->mode() == ManualSync::ALL_REDUCE ? "sync/all_reduce"
+                                                                        : "sync/gather_scatter");
+        manual_sync_->run(stream);
+    }
+    optimizer_step(lr, momentum, weight_decay, grad_scale, stream);
 }
 
 void VggEngine::eval_step(const uint16_t* x, const int64_t* target, int batch, hipStream_t stream) {
@@ -687,6 +712,8 @@ void VggEngine::replay_train_step(hipStream_t stream) {
 
 // ------------------------------------------------------------------------- bindings
 void bind_engine(py::module_& m) {
+    m.def("set_trace_ranges", &set_trace_ranges);
+    m.def("trace_ranges_enabled", &trace_ranges_enabled);
     py::class_<SlotInfo>(m, "SlotInfo")
         .def_readonly("name", &SlotInfo::name)
         .def_readonly("offset", &SlotInfo::offset)
@@ -731,6 +758,13 @@ void bind_engine(py::module_& m) {
         .def("forward_backward", [](VggEngine& e, uintptr_t x, uintptr_t t, int batch, uintptr_t s) {
             e.forward_backward((const uint16_t*)x, (const int64_t*)t, batch, (hipStream_t)s);
         })
+        .def("train_step", [](VggEngine& e, uintptr_t x, uintptr_t t, int batch, float lr, float mu,
+                              float wd, float gs, uintptr_t s) {
+            e.train_step((const uint16_t*)x, (const int64_t*)t, batch, lr, mu, wd, gs,
+                         (hipStream_t)s);
+        })
+        .def("set_manual_sync", [](VggEngine& e, ManualSync* m) { e.set_manual_sync(m); },
+             py::keep_alive<1, 2>())
         .def("optimizer_step", [](VggEngine& e, float lr, float mu, float wd, float gs, uintptr_t s) {
             e.optimizer_step(lr, mu, wd, gs, (hipStream_t)s);
         })

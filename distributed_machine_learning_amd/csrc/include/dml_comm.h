@@ -57,42 +57,153 @@ class TcpStore {
     std::mutex client_mu_;
 };
 
-// ------------------------------------------------------------------------ RcclComm
+// ---------------------------------------------------------------------------- Comm
 enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_I64 = 2, DT_U8 = 3 };
+size_t dtype_bytes(DType dt);
 
-class RcclComm {
+// The collective surface of the three sync modes.  Every call enqueues on the caller's HIP
+// stream and returns; calls on one communicator must be issued in the same order on every rank.
+//
+// Two transports implement it.  RcclComm is the product path (RCCL over xGMI, one process per
+// GPU).  LoopbackComm exists for tests only: RCCL refuses two ranks on one device ("Duplicate
+// GPU detected"), so on a single-GPU machine it is the only way to run the engine, the bucket
+// reducer and the sync strategies with more than one rank.
+class Comm {
+  public:
+    virtual ~Comm() {}
+    int rank() const { return rank_; }
+    int world_size() const { return world_; }
+    virtual const char* transport() const = 0;
+    // number of ranks the transport itself reports for this communicator (ncclCommCount)
+    virtual int peer_count() = 0;
+
+    virtual void all_reduce(void* buf, size_t count, DType dt, bool average,
+                            hipStream_t stream) = 0;
+    // root sends `send`, every rank (root included) receives into `recv` (may alias `send`)
+    virtual void broadcast(const void* send, void* recv, size_t count, DType dt, int root,
+                           hipStream_t stream) = 0;
+    void broadcast(void* buf, size_t count, DType dt, int root, hipStream_t stream) {
+        broadcast(buf, buf, count, dt, root, stream);
+    }
+    // root receives rank r's `send` into recv[r]; its own contribution is a device copy
+    virtual void gather(const void* send, const std::vector<void*>& recv, size_t count, DType dt,
+                        int root, hipStream_t stream) = 0;
+    // rank r receives root's chunks[r] into `out`
+    virtual void scatter(void* out, const std::vector<const void*>& chunks, size_t count,
+                         DType dt, int root, hipStream_t stream) = 0;
+    // calls between group_start / group_end may be fused into one launch by the transport
+    virtual void group_start() {}
+    virtual void group_end() {}
+    // Host-side wait for `stream` with a deadline; on expiry or an asynchronous transport error
+    // the communicator is aborted and std::runtime_error is thrown, so a dead peer turns
+    // into a clean non-zero exit instead of a hang.
+    virtual void wait_stream(hipStream_t stream, double timeout_s) = 0;
+    virtual void destroy() = 0;
+
+  protected:
+    Comm(int rank, int world) : rank_(rank), world_(world) {}
+    int rank_, world_;
+};
+
+// ------------------------------------------------------------------------ RcclComm
+class RcclComm : public Comm {
   public:
     static std::string unique_id();     // 128 opaque bytes, created on rank 0
     RcclComm(const std::string& unique_id, int rank, int world_size, int device);
-    ~RcclComm();
+    ~RcclComm() override;
 
-    int rank() const { return rank_; }
-    int world_size() const { return world_; }
-
-    void all_reduce(void* buf, size_t count, DType dt, bool average, hipStream_t stream);
-    void broadcast(void* buf, size_t count, DType dt, int root, hipStream_t stream);
-    // out-of-place form: root sends `send`, every rank (root included) receives into `recv`
+    const char* transport() const override { return "rccl"; }
+    int peer_count() override;
+    void all_reduce(void* buf, size_t count, DType dt, bool average, hipStream_t stream) override;
+    using Comm::broadcast;
     void broadcast(const void* send, void* recv, size_t count, DType dt, int root,
-                   hipStream_t stream);
-    // root receives rank r's `send` into recv[r]; its own contribution is a device copy
+                   hipStream_t stream) override;
     void gather(const void* send, const std::vector<void*>& recv, size_t count, DType dt,
-                int root, hipStream_t stream);
-    // rank r receives root's chunks[r] into `out`
+                int root, hipStream_t stream) override;
     void scatter(void* out, const std::vector<const void*>& chunks, size_t count, DType dt,
-                 int root, hipStream_t stream);
-    void group_start();
-    void group_end();
-    // Host-side wait for `stream` with a deadline; on expiry or an asynchronous RCCL error
-    // the communicator is aborted and std::runtime_error is thrown, so a dead peer turns
-    // into a clean non-zero exit instead of a hang.
-    void wait_stream(hipStream_t stream, double timeout_s);
-    void destroy();
+                 int root, hipStream_t stream) override;
+    void group_start() override;
+    void group_end() override;
+    void wait_stream(hipStream_t stream, double timeout_s) override;
+    void destroy() override;
     void* raw() const { return comm_; }
 
   private:
     void* comm_ = nullptr;      // ncclComm_t
-    int rank_, world_, device_;
+    int device_;
     int group_depth_ = 0;
+    // root-side self copies of gather / scatter calls made inside an open group: issued when
+    // the group closes, so they never interleave with the grouped transfers
+    struct SelfCopy { void* dst; const void* src; size_t bytes; hipStream_t stream; };
+    std::vector<SelfCopy> deferred_copies_;
+};
+
+// -------------------------------------------------------------------- LoopbackComm
+// TEST TRANSPORT.  Ranks are processes that may all sit on ONE GPU; a collective stages its
+// payload through a POSIX shared-memory segment in chunks.  It keeps the property the engine's
+// choreography depends on - a collective is stream-ordered and asynchronous to the host: the
+// call enqueues a "ready" flag kernel and a "wait" kernel on the caller's stream and hands the
+// operation to a helper thread, which waits for the flag, copies device -> host, exchanges and
+// reduces with its peers (in rank order: every rank computes bit-identical sums), copies the
+// result back and releases the wait kernel.  Operations are served in issue order whatever
+// stream they were issued on, which is also what RCCL does for one communicator.
+class LoopbackComm : public Comm {
+  public:
+    // `name` identifies the job (all ranks pass the same string, e.g. the rendezvous port)
+    LoopbackComm(const std::string& name, int rank, int world_size, int device, double timeout_s);
+    ~LoopbackComm() override;
+
+    const char* transport() const override { return "loopback"; }
+    int peer_count() override;
+    void all_reduce(void* buf, size_t count, DType dt, bool average, hipStream_t stream) override;
+    using Comm::broadcast;
+    void broadcast(const void* send, void* recv, size_t count, DType dt, int root,
+                   hipStream_t stream) override;
+    void gather(const void* send, const std::vector<void*>& recv, size_t count, DType dt,
+                int root, hipStream_t stream) override;
+    void scatter(void* out, const std::vector<const void*>& chunks, size_t count, DType dt,
+                 int root, hipStream_t stream) override;
+    void wait_stream(hipStream_t stream, double timeout_s) override;
+    void destroy() override;
+
+  private:
+    struct Impl;
+    Impl* impl_;
+};
+
+// stream-side flag kernels of the loopback transport (loopback_flags.hip)
+void loopback_enqueue_signal(unsigned* flag, unsigned value, hipStream_t stream);
+void loopback_enqueue_wait(const unsigned* flag, unsigned value, unsigned* timed_out,
+                           long long max_ticks, hipStream_t stream);
+
+// --------------------------------------------------------------------- ManualSync
+// The two gradient synchronisations the reference runs between backward and optimizer.step(),
+// driven from C++ over the flat gradient buffer (no per-tensor Python in the step):
+//   GATHER_SCATTER  per parameter tensor: gather on rank `root`, sum there, scatter the sum back
+//                   (/root/reference/part2/2a/main.py:89-116)
+//   ALL_REDUCE      per parameter tensor: all_reduce(SUM)  (/root/reference/part2/2b/main.py:101-106)
+// Both keep one collective per tensor (fused into one launch by a group) and leave the SUM in
+// the gradient buffer; a mean is folded into the optimizer's gradient scale by the caller.
+class ManualSync {
+  public:
+    enum Mode : int { GATHER_SCATTER = 0, ALL_REDUCE = 1 };
+    struct Slice { size_t offset, count; };
+    // `root_slabs`: on the root of GATHER_SCATTER, world_size * slab_stride floats of landing
+    // area (slab r holds rank r's gradients, tensors packed back to back); ignored otherwise.
+    ManualSync(Comm* comm, Mode mode, float* flat_grads, std::vector<Slice> tensors, int root,
+               float* root_slabs, size_t slab_stride);
+    void run(hipStream_t stream);
+    Mode mode() const { return mode_; }
+    static size_t packed_elems(const std::vector<Slice>& tensors);    // slab_stride needed
+
+  private:
+    Comm* comm_;
+    Mode mode_;
+    float* grads_;
+    std::vector<Slice> tensors_;
+    int root_;
+    float* slabs_;
+    size_t stride_;
 };
 
 // ------------------------------------------------------------------- bucket planning
@@ -121,7 +232,7 @@ class BucketReducer {
     struct Slice { size_t offset, count; };
     // compute_stream: the stream backward runs on (the communication stream is chosen to
     // execute concurrently with it)
-    BucketReducer(RcclComm* comm, float* flat_grads, std::vector<Slice> slices, bool average,
+    BucketReducer(Comm* comm, float* flat_grads, std::vector<Slice> slices, bool average,
                   bool serialize, hipStream_t compute_stream = nullptr);
     ~BucketReducer();
     int num_buckets() const { return (int)slices_.size(); }
@@ -134,6 +245,14 @@ class BucketReducer {
                       bool in_line = false);
     void wait_all(hipStream_t compute);
     hipStream_t comm_stream() const { return comm_stream_; }
+    // Send gradients as bf16: `wire` is a bf16 buffer as long as the flat gradient buffer (same
+    // element offsets).  A bucket is rounded into it, summed there and widened back into the
+    // fp32 gradients, all on the stream that runs its collective.  nullptr: fp32 on the wire.
+    void set_bf16_payload(uint16_t* wire);
+    // Whether a bucket marked `in_line` really runs on the compute stream (default) or goes
+    // through the communication stream like every other bucket.
+    void set_inline_last(bool on) { inline_last_ = on; }
+    bool inline_last() const { return inline_last_; }
 
     void set_buffer_sync(float* buffers, float* staging, size_t count);
     void buffers_updated(hipStream_t compute);      // call after the forward pass
@@ -150,10 +269,13 @@ class BucketReducer {
     }
 
   private:
-    RcclComm* comm_;
+    void reduce_slice(int b, hipStream_t stream);
+    Comm* comm_;
     float* grads_;
     std::vector<Slice> slices_;
     bool average_, serialize_;
+    bool inline_last_ = true;
+    uint16_t* wire_ = nullptr;
     hipStream_t comm_stream_ = nullptr;
     std::vector<hipEvent_t> ready_, done_;
     std::vector<char> launched_;

@@ -79,6 +79,11 @@ class VggEngine {
     // waits for the reducer (if any), fused SGD over the flat buffers, refresh_weights
     void optimizer_step(float lr, float momentum, float weight_decay, float grad_scale,
                         hipStream_t stream);
+    // One whole iteration in one call: forward_backward, the manual gradient synchronisation
+    // if one is attached (set_manual_sync), optimizer_step.
+    void train_step(const uint16_t* x_nhwc4, const int64_t* target, int batch, float lr,
+                    float momentum, float weight_decay, float grad_scale, hipStream_t stream);
+    void set_manual_sync(ManualSync* sync) { manual_sync_ = sync; }
     // forward only (evaluation statistics); accumulates loss / correct into the eval slots
     void eval_step(const uint16_t* x_nhwc4, const int64_t* target, int batch, hipStream_t stream);
     void forward(const uint16_t* x_nhwc4, int batch, bool training, hipStream_t stream);
@@ -149,6 +154,7 @@ class VggEngine {
     float *params_ = nullptr, *grads_ = nullptr, *mom_ = nullptr, *bnbuf_ = nullptr, *ws_ = nullptr;
     uint16_t* arena_ = nullptr;
     BucketReducer* reducer_ = nullptr;
+    ManualSync* manual_sync_ = nullptr;
     std::vector<std::vector<int>> buckets_by_layer_;   // layer -> bucket ids to fire
     long long bn_steps_ = 0;
     bool wgrad_overlap_ = false;

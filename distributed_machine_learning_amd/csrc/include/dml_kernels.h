@@ -242,6 +242,8 @@ void sgd_momentum(float* p, const float* g, float* m, bf16_raw* shadow, size_t n
 
 // out[i] = bf16(x[i])
 void cast_f32_to_bf16(const float* x, bf16_raw* out, size_t n, hipStream_t stream);
+// out[i] = float(x[i])   (n a multiple of 4)
+void cast_bf16_to_f32(const bf16_raw* x, float* out, size_t n, hipStream_t stream);
 
 // ---------------------------------------------------------------- data / layout / comm helpers
 // uint8 [B,32,32,3] -> bf16 [B,32,32,4], random-crop(pad 4)+flip per aug row (may be null),

@@ -87,6 +87,31 @@ void cast_f32_to_bf16(const float* x, bf16_raw* out, size_t n, hipStream_t strea
                        (const float4*)x, (uint2*)out, n4);
 }
 
+__global__ __launch_bounds__(256) void cast_bf16_to_f32_kernel(const uint2* __restrict__ x,
+                                                               float4* __restrict__ out, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        const uint2 v = x[i];
+        float4 o;
+        o.x = __uint_as_float(v.x << 16);
+        o.y = __uint_as_float(v.x & 0xffff0000u);
+        o.z = __uint_as_float(v.y << 16);
+        o.w = __uint_as_float(v.y & 0xffff0000u);
+        out[i] = o;
+    }
+}
+
+void cast_bf16_to_f32(const bf16_raw* x, float* out, size_t n, hipStream_t stream) {
+    if (n % 4 != 0) throw std::invalid_argument("cast_bf16_to_f32: n must be a multiple of 4");
+    if (n == 0) return;
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       (const uint2*)x, (float4*)out, n4);
+}
+
 // ---------------------------------------------------------------------------- linear
 // out_features <= 16 (10 here): far too narrow for MFMA tiles.  One wave per batch row;
 // each lane owns a contiguous slice of K, keeps `out_features` partial dots in registers

@@ -1,9 +1,10 @@
-"""Native execution backend: the C++ ``VggEngine`` plus the RCCL sync strategies.
+"""Native execution backend: the C++ ``VggEngine`` plus the native sync strategies.
 
-One training step = ``engine.forward_backward`` (zero_grad, forward, loss, backward with
-the bucket reducer's hooks) -> manual sync strategy if selected -> ``engine.optimizer_step``
-(reducer wait, fused SGD, bf16 weight shadows), all enqueued on torch's current stream;
-the reference's equivalent sequence is /root/reference/part2/2b/main.py:52-62.
+One training step is ONE call into C++, ``engine.train_step``: forward, loss, backward (with
+the bucket reducer's hooks between layers in the DDP mode), the manual gradient
+synchronisation of the gather/scatter and all-reduce modes (``ManualSync``), then the fused
+SGD and the weight repacks - all enqueued on torch's current stream; the reference's
+equivalent sequence is /root/reference/part2/2b/main.py:52-62.
 
 Flat buffers are torch tensors so parameters can be viewed, broadcast, checkpointed and
 compared against the stock-torch model; their internal layout (conv weights
@@ -20,7 +21,6 @@ from ..models.vgg import VGG, VGG_WIDTHS
 from ..ops import native
 from ..parallel.comm import Communicator
 from ..parallel.flat import cap_tail_bucket
-from ..parallel.strategies import AllReduceSync, GatherScatterSync, GradSync, NoSync
 
 
 class NativeBackend:
@@ -54,6 +54,7 @@ class NativeBackend:
         self.slots = list(e.param_slots)
         self.buffer_slots = list(e.buffer_slots)
         self._loss_off = e.loss_offset
+        self._loss_view = self.workspace[e.loss_offset:e.loss_offset + 1]
         self._training = True
         # initial weights: the stock module's initialisers under the caller's seed, so every
         # backend (and every rank) starts from the same numbers the reference would
@@ -61,8 +62,12 @@ class NativeBackend:
             init_state = VGG(cfg.arch, cfg.batch_norm, cfg.num_classes).state_dict()
         self.load_state_dict(init_state)
         self.reducer = None
+        self.manual = None
         self._grad_scale = 1.0
-        self.sync = self._build_sync()
+        self._comm_on = True
+        if self.world > 1:
+            self._verify_replicas()
+        self._build_sync()
         # after the reducer exists: the side stream must share a hardware queue with neither
         # the compute stream nor the communication stream
         # layers per hand-off (each costs ~15 us of host time and a cross-queue hop): one layer
@@ -73,8 +78,7 @@ class NativeBackend:
         # the optimizer update can run inside backward when the gradients backward leaves
         # behind are final: no sync, or the bucket reducer (the two manual modes synchronise
         # after backward has ended)
-        self._fuse_opt = bool(cfg.fused_optimizer) and e.wgrad_overlap and \
-            isinstance(self.sync, NoSync)
+        self._fuse_opt = bool(cfg.fused_optimizer) and e.wgrad_overlap and self.manual is None
         self._graph_ready = False
         self._x_static = None
         self._t_static = None
@@ -83,17 +87,56 @@ class NativeBackend:
     def _grad_views(self) -> List[torch.Tensor]:
         return [self.grads[s.offset:s.offset + s.numel] for s in self.slots]
 
-    def _build_sync(self) -> GradSync:
+    def _verify_replicas(self) -> None:
+        """Every rank must hold the same model before gradients are exchanged: a mismatch
+        would pair up unrelated gradient elements (or hang in a collective of different
+        length).  DistributedDataParallel's constructor makes the same check
+        (/root/reference/part3/main.py:137); here it covers all three sync modes."""
+        e, cfg = self.engine, self.cfg
+        mine = [len(self.slots), int(e.param_elems), int(e.bn_elems), int(cfg.batch_norm),
+                sum((i + 1) * int(s.numel) for i, s in enumerate(self.slots)) % (1 << 40)]
+        t = torch.tensor(mine, dtype=torch.int64, device=self.device)
+        ref = t.clone()
+        self.comm.broadcast(ref, 0)
+        bad = torch.zeros(1, dtype=torch.int64, device=self.device)
+        bad[0] = int(not torch.equal(ref, t))
+        self.comm.all_reduce(bad)
+        self.comm.guard_sync(self.cfg.comm_timeout_s)
+        if int(bad.item()):
+            raise RuntimeError(
+                f"[rank {self.comm.rank}] model layout differs between ranks: mine "
+                f"(slots, parameter elements, buffer elements, batch_norm, shape checksum) = "
+                f"{mine}, rank 0 has {ref.tolist()}")
+
+    def _tensor_slices(self):
+        return [(int(s.offset), int(s.numel)) for s in self.slots]
+
+    def _build_sync(self) -> None:
         cfg, comm = self.cfg, self.comm
         reduce = cfg.resolved_grad_reduce()
+        C = native.lib()
+        self.sync_name = cfg.sync if comm is not None else SYNC_NONE
         if cfg.sync == SYNC_NONE or comm is None:
-            return NoSync(comm, reduce)
-        if cfg.sync == SYNC_GATHER_SCATTER:
-            return GatherScatterSync(comm, self._grad_views(), reduce)
-        if cfg.sync == SYNC_ALL_REDUCE:
-            return AllReduceSync(comm, self._grad_views(), reduce)
+            return
+        # collectives sum; the 1/world of "mean" is folded into the fused SGD kernel's gradient
+        # scale, where it is free
+        self._grad_scale = 1.0 / self.world if reduce == "mean" else 1.0
+        if cfg.sync in (SYNC_GATHER_SCATTER, SYNC_ALL_REDUCE):
+            tensors = self._tensor_slices()
+            slabs, stride = 0, 0
+            if cfg.sync == SYNC_GATHER_SCATTER and comm.rank == 0:
+                # root-side landing area, allocated once (the reference allocates fresh zero
+                # tensors every iteration, part2/2a/main.py:96-98,112)
+                stride = int(C.ManualSync.packed_elems(tensors))
+                self._slab_store = torch.zeros(self.world, stride, dtype=torch.float32,
+                                               device=self.device)
+                slabs = self._slab_store.data_ptr()
+            mode = 0 if cfg.sync == SYNC_GATHER_SCATTER else 1
+            self.manual = C.ManualSync(comm.native, mode, self.grads.data_ptr(), tensors, 0,
+                                       slabs, stride)
+            self.engine.set_manual_sync(self.manual)
+            return
         if cfg.sync == SYNC_DDP:
-            C = native.lib()
             sizes = [s.numel * 4 for s in self.slots]
             buckets = C.plan_buckets(sizes, int(cfg.bucket_cap_mb * (1 << 20)),
                                      int(cfg.first_bucket_cap_mb * (1 << 20)))
@@ -117,11 +160,20 @@ class NativeBackend:
                 slices.append((start, end - start))
             self.buckets = buckets
             self._bucket_slices = slices
-            # buckets are summed (RCCL's plain-sum path); the 1/world of "mean" is folded into
-            # the fused SGD kernel's gradient scale, where it is free
             self.reducer = C.BucketReducer(comm.native, self.grads.data_ptr(), slices, False,
                                            cfg.serialize_streams, self._stream())
-            self._grad_scale = 1.0 / self.world if reduce == "mean" else 1.0
+            # The bucket that completes with the end of backward can run on the compute stream
+            # itself (two cross-queue hand-offs fewer).  With more than one rank it goes through
+            # the communication stream like the others unless asked: one stream per communicator
+            # is the pattern every RCCL user exercises.
+            inline = cfg.inline_last_bucket
+            self.reducer.inline_last = (self.world == 1) if inline is None else bool(inline)
+            if cfg.grad_comm_dtype == "bf16":
+                self._wire = torch.zeros(self.grads.numel(), dtype=torch.bfloat16,
+                                         device=self.device)
+                self.reducer.set_bf16_payload(self._wire.data_ptr())
+            elif cfg.grad_comm_dtype != "fp32":
+                raise ValueError(f"grad_comm_dtype must be fp32 or bf16, got {cfg.grad_comm_dtype}")
             self.engine.set_reducer(self.reducer, buckets)
             if stage:
                 # DDP's per-forward buffer broadcast: rank 0's running statistics ride in the
@@ -134,31 +186,39 @@ class NativeBackend:
                 if cfg.batch_norm:
                     comm.broadcast(self.bn_buffers, 0)
                 self.engine.refresh_weights(self._stream())
-            return NoSync(comm, reduce)
+            return
         raise ValueError(cfg.sync)
+
+    def sync_plan(self):
+        """What the step synchronises, for logs and benchmark records."""
+        plan = {"mode": self.sync_name, "grad_scale": self._grad_scale}
+        if self.reducer is not None:
+            plan["buckets_mb"] = [round(c * 4 / (1 << 20), 3) for _, c in self._bucket_slices]
+            plan["inline_last_bucket"] = bool(self.reducer.inline_last)
+            plan["wire_dtype"] = self.cfg.grad_comm_dtype
+        if self.manual is not None:
+            plan["collectives_per_step"] = len(self.slots) * (2 if self.sync_name ==
+                                                               SYNC_GATHER_SCATTER else 1)
+        return plan
 
     # ------------------------------------------- communication / compute accounting
     def set_comm_enabled(self, on: bool) -> None:
         """Detach (or re-attach) every gradient collective while keeping the rest of the step
         identical - the compute-only baseline of the overlap report.  Ranks drift apart while
         detached; only use it for timing."""
-        if on:
-            self.sync = self._sync_saved
-            if self.reducer is not None:
-                self.engine.set_reducer(self.reducer, self.buckets)
-        else:
-            self._sync_saved = self.sync
-            self.sync = NoSync(self.comm, self.cfg.resolved_grad_reduce())
-            if self.reducer is not None:
-                self.engine.set_reducer(None, [])
+        self._comm_on = on
+        if self.reducer is not None:
+            self.engine.set_reducer(self.reducer if on else None, self.buckets if on else [])
+        if self.manual is not None:
+            self.engine.set_manual_sync(self.manual if on else None)
 
     def comm_only_step(self) -> None:
         """Issue exactly the gradient collectives of one step, nothing else."""
         if self.reducer is not None:
             for start, count in self._bucket_slices:
                 self.comm.all_reduce(self.grads[start:start + count], "sum")
-        else:
-            self.sync.finish()
+        elif self.manual is not None:
+            self.manual.run(self._stream())
 
     # ------------------------------------------------------------------ steps
     @staticmethod
@@ -187,10 +247,9 @@ class NativeBackend:
                               self._grad_scale)
         if cfg.use_graph and self.world == 1:
             return self._train_step_graph(data, target, n, s)
-        e.forward_backward(data.data_ptr(), target.data_ptr(), n, s)
-        self.sync.finish()
-        e.optimizer_step(cfg.lr, cfg.momentum, cfg.weight_decay, self._grad_scale, s)
-        return self.workspace[self._loss_off:self._loss_off + 1]
+        e.train_step(data.data_ptr(), target.data_ptr(), n, cfg.lr, cfg.momentum, cfg.weight_decay,
+                     self._grad_scale, s)
+        return self._loss_view
 
     def _train_step_graph(self, data, target, n, s):
         cfg, e = self.cfg, self.engine
@@ -287,4 +346,6 @@ class NativeBackend:
     def close(self) -> None:
         torch.cuda.synchronize()
         self.engine.set_reducer(None, [])
+        self.engine.set_manual_sync(None)
         self.reducer = None
+        self.manual = None

@@ -74,6 +74,11 @@ class Trainer:
         self.world = comm.world_size if comm is not None else 1
         self.backend = make_backend(cfg, device, comm)
         self.cfg = self.backend.cfg
+        if cfg.profile_ranges and self.backend.name == "native":
+            # per-phase roctx ranges from inside the C++ step (forward / backward / wgrad side
+            # stream / buckets / sync / optimizer) in addition to the per-iteration one below
+            from ..ops import native
+            native.lib().set_trace_ranges(True)
         self.last_timer: Optional[IterationTimer] = None
         self.losses: Dict[int, float] = {}
 

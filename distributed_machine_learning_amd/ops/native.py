@@ -10,6 +10,7 @@ to build it, so a GPU run can never silently use stock torch ops.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -30,6 +31,13 @@ def lib():
             raise ImportError(
                 "native extension distributed_machine_learning_amd/_C*.so is missing or does not "
                 "load; build it with `python build.py` (hipcc, gfx950)") from exc
+        if os.environ.get("DML_SKIP_BUILD_CHECK") != "1":
+            from ..buildinfo import tree_hash
+            want, have = tree_hash(), getattr(_C, "build_id", "")
+            if want != have:
+                raise ImportError(
+                    f"native extension is stale: built from sources {have or 'unknown'}, the "
+                    f"tree next to it hashes to {want}; run `python build.py`")
         _LIB = _C
     return _LIB
 

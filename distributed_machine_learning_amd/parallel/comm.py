@@ -7,15 +7,16 @@ part3/main.py:148-161) and uses exactly four collectives: gather, scatter,
 all_reduce(SUM) and DDP's broadcast (part2/2a/main.py:101,114, part2/2b/main.py:106,
 part3/main.py:137).
 
-Two transports implement one interface, selected by where the tensors live:
+Here the process group is ``RcclCommunicator``: a native RCCL communicator
+(csrc/comm/rccl_comm.cpp) bootstrapped by publishing the ``ncclUniqueId`` through the
+native TCP key-value store bound to ``--master-ip host:port`` (csrc/comm/tcp_store.cpp).
+Tensors live in GPU memory; collectives are enqueued on a HIP stream and never block the
+host; every host-side wait has a deadline.  There is no host-memory transport: a run on
+the CPU device is single-process.
 
-* ``RcclCommunicator`` - tensors in GPU memory.  A native RCCL communicator
-  (csrc/comm/rccl_comm.cpp) bootstrapped by publishing the ``ncclUniqueId`` through
-  the native TCP key-value store bound to ``--master-ip host:port``
-  (csrc/comm/tcp_store.cpp).  Collectives are enqueued on a HIP stream and never
-  block the host.
-* ``HostCommunicator`` - tensors in host memory (the CPU configuration and the
-  multi-process tests that run without a GPU): ``torch.distributed`` with gloo.
+``transport="loopback"`` swaps RCCL for the native test transport (csrc/comm/
+loopback_comm.cpp) that lets several ranks share ONE GPU - RCCL itself refuses that - so the
+multi-rank behaviour of the engine can be tested on a single-GPU machine.
 """
 from __future__ import annotations
 
@@ -84,88 +85,45 @@ class _Done:
         return None
 
 
-class HostCommunicator(Communicator):
-    """gloo over TCP for host tensors."""
-
-    def __init__(self, master_ip: str, rank: int, world_size: int, timeout_s: float = 300.0):
-        import torch.distributed as dist
-        self._dist = dist
-        self._owns_group = not dist.is_initialized()
-        if self._owns_group:
-            if os.environ.get("TORCHELASTIC_RUN_ID") and "MASTER_ADDR" in os.environ:
-                init = "env://"
-            else:
-                init = "tcp://" + master_ip
-            dist.init_process_group("gloo", init_method=init, world_size=world_size, rank=rank,
-                                    timeout=datetime.timedelta(seconds=timeout_s))
-        self.rank = dist.get_rank()
-        self.world_size = dist.get_world_size()
-        self.backend = dist.get_backend()
-
-    def _finish(self, tensor, op):
-        if op == "mean":
-            tensor.div_(self.world_size)
-
-    def all_reduce(self, tensor, op="sum"):
-        assert op in _REDUCE_OPS
-        self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM)
-        self._finish(tensor, op)
-
-    def all_reduce_async(self, tensor, op="sum"):
-        assert op in _REDUCE_OPS
-        work = self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, async_op=True)
-        comm = self
-
-        class _Handle:
-            def wait(self_inner):
-                work.wait()
-                comm._finish(tensor, op)
-        return _Handle()
-
-    def gather(self, tensor, slabs, root=0):
-        self._dist.gather(tensor, list(slabs) if self.rank == root else None, dst=root)
-
-    def scatter(self, out, chunks, root=0):
-        self._dist.scatter(out, list(chunks) if self.rank == root else None, src=root)
-
-    def broadcast(self, tensor, root=0):
-        self._dist.broadcast(tensor, src=root)
-
-    def barrier(self):
-        self._dist.barrier()
-
-    def destroy(self):
-        if self._owns_group and self._dist.is_initialized():
-            self._dist.destroy_process_group()
-
-
 class RcclCommunicator(Communicator):
-    """Native RCCL communicator for device tensors.
+    """Native communicator for device tensors (RCCL; ``transport="loopback"`` for tests).
 
     Every call enqueues on ``stream`` (default: torch's current stream) and returns
     immediately; ordering against compute is by stream order or by the events the
     bucket reducer records.  ``mean`` is implemented with ``ncclAvg``.
     """
 
-    backend = "rccl"
-
     def __init__(self, master_ip: str, rank: int, world_size: int, device_index: int,
-                 timeout_s: float = 300.0):
+                 timeout_s: float = 300.0, transport: Optional[str] = None):
         from ..ops import native
         self._C = native.lib()
         self.rank = rank
         self.world_size = world_size
         self.device_index = device_index
+        self.timeout_s = float(timeout_s)
+        self.transport = transport or os.environ.get("DML_TRANSPORT", "rccl")
+        self.backend = self.transport
+        self._store = None
         torch.cuda.set_device(device_index)
-        uid = self._exchange_unique_id(master_ip, rank, world_size, timeout_s)
-        self._comm = self._C.RcclComm(uid, rank, world_size, device_index)
+        if self.transport == "rccl":
+            uid = self._exchange_unique_id(master_ip, rank, world_size, timeout_s)
+            self._comm = self._C.RcclComm(uid, rank, world_size, device_index)
+        elif self.transport == "loopback":
+            _, port = split_host_port(master_ip)
+            self._comm = self._C.LoopbackComm(str(port), rank, world_size, device_index,
+                                              float(timeout_s))
+        else:
+            raise ValueError(f"unknown transport {self.transport!r} (rccl | loopback)")
+        if self._comm.peer_count != world_size:
+            raise RuntimeError(f"{self.transport} communicator reports {self._comm.peer_count} "
+                               f"ranks, expected {world_size}")
 
     # -- bootstrap ---------------------------------------------------------------
     def _exchange_unique_id(self, master_ip, rank, world_size, timeout_s) -> bytes:
         """Rank 0 creates the id and publishes it; everyone else fetches it.
 
-        Stand-alone launches (one process per rank started by hand or by
-        ``launch.py``, like the reference) use the native TCP store listening on
+        Stand-alone launches (one process per rank started by hand, by ``launch.py`` or by
+        ``bench.py`` itself, like the reference) use the native TCP store listening on
         ``master_ip``.  Under ``torchrun`` that port already belongs to the launcher's
         own rendezvous store, which hands workers a client connection; the id is
         published there instead of opening a second listener on a guessed port.
@@ -182,7 +140,6 @@ class RcclCommunicator(Communicator):
                 store.set(key, uid)
             else:
                 uid = bytes(store.get(key))
-            self._store = None
             return uid
         host, port = split_host_port(master_ip)
         self._store = self._C.TcpStore(host, port, rank == 0, world_size, float(timeout_s))
@@ -211,12 +168,12 @@ class RcclCommunicator(Communicator):
             return 2
         if t.dtype == torch.uint8:
             return 3
-        raise TypeError(f"unsupported dtype for RCCL: {t.dtype}")
+        raise TypeError(f"unsupported dtype for a collective: {t.dtype}")
 
     @staticmethod
     def _check(t: torch.Tensor):
         if not (t.is_cuda and t.is_contiguous()):
-            raise ValueError("RCCL collectives need contiguous device tensors")
+            raise ValueError("collectives need contiguous device tensors")
 
     # -- collectives -------------------------------------------------------------
     def all_reduce(self, tensor, op="sum", stream=None):
@@ -246,13 +203,24 @@ class RcclCommunicator(Communicator):
         self._comm.broadcast(tensor.data_ptr(), tensor.numel(), self._dtype_code(tensor),
                              root, self._stream(stream))
 
-    def barrier(self):
+    def barrier(self, timeout_s: Optional[float] = None):
+        """All ranks have reached this point and the current stream has drained.  Bounded:
+        a lost peer raises (and aborts the communicator) instead of hanging every survivor."""
         token = torch.zeros(1, device=f"cuda:{self.device_index}")
         self.all_reduce(token)
-        torch.cuda.current_stream().synchronize()
+        self.guard_sync(self.timeout_s if timeout_s is None else timeout_s)
 
     def guard_sync(self, timeout_s: float = 300.0) -> None:
         self._comm.wait_stream(self._stream(), float(timeout_s))
+
+    def all_gather_scalars(self, value, dtype=torch.int64) -> torch.Tensor:
+        """One scalar per rank, visible to every rank (a W-vector summed with one non-zero
+        entry per rank); returns the host tensor.  For self-checks, not for the step."""
+        v = torch.zeros(self.world_size, dtype=dtype, device=f"cuda:{self.device_index}")
+        v[self.rank] = value
+        self.all_reduce(v)
+        self.guard_sync(self.timeout_s)
+        return v.cpu()
 
     def group_start(self):
         self._comm.group_start()
@@ -264,6 +232,10 @@ class RcclCommunicator(Communicator):
     def native(self):
         return self._comm
 
+    @property
+    def peer_count(self) -> int:
+        return int(self._comm.peer_count)
+
     def destroy(self):
         if self._comm is not None:
             torch.cuda.synchronize()
@@ -274,8 +246,11 @@ class RcclCommunicator(Communicator):
 
 def init_communicator(master_ip: str, rank: int, world_size: int, device: torch.device,
                       timeout_s: float = 300.0) -> Communicator:
-    """Pick the transport from the device the model trains on."""
-    if device.type == "cuda":
-        index = device.index if device.index is not None else torch.cuda.current_device()
-        return RcclCommunicator(master_ip, rank, world_size, index, timeout_s)
-    return HostCommunicator(master_ip, rank, world_size, timeout_s)
+    """Join the process group.  Gradient synchronisation runs on RCCL between GPUs; there is
+    no host-memory transport, so a CPU run cannot take part in one."""
+    if device.type != "cuda":
+        raise RuntimeError(
+            "gradient synchronisation (--sync gather_scatter | all_reduce | ddp) needs one "
+            "MI355X per rank: the only transport is RCCL.  On the CPU device run --sync none.")
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    return RcclCommunicator(master_ip, rank, world_size, index, timeout_s)

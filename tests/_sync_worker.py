@@ -1,16 +1,21 @@
 """Worker for the multi-process sync tests: trains a few steps on synthetic data and
-writes the final flat parameter vector (and BN buffers) of its rank to --out."""
+writes the final flat parameter vector (and BN buffers) of its rank to --out.
+
+On the CPU device the process group is the gloo TEST DOUBLE of tests/support (the package has
+no host-memory transport); on a GPU it is the package's own communicator, RCCL or - with
+--transport loopback - the native test transport that lets ranks share one GPU."""
 import argparse
 import os
 import sys
 
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.abspath(os.path.dirname(__file__)))
 
 import torch  # noqa: E402
 
 from distributed_machine_learning_amd.config import TrainConfig  # noqa: E402
 from distributed_machine_learning_amd.engine.trainer import Trainer  # noqa: E402
-from distributed_machine_learning_amd.parallel.comm import init_communicator  # noqa: E402
+from distributed_machine_learning_amd.parallel.comm import RcclCommunicator  # noqa: E402
 
 
 def main():
@@ -28,23 +33,46 @@ def main():
     ap.add_argument("--dtype", default="fp32")
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--report-overlap", action="store_true")
+    ap.add_argument("--transport", default="rccl")
+    ap.add_argument("--bucket-cap-mb", type=float, default=25.0)
+    ap.add_argument("--grad-comm-dtype", default="fp32")
+    ap.add_argument("--inline-last-bucket", type=int, default=None)
+    ap.add_argument("--serialize-streams", action="store_true")
+    ap.add_argument("--arch", default="VGG11")
     ap.add_argument("--out", required=True)
     ns = ap.parse_args()
     cfg = TrainConfig(master_ip=ns.master_ip, rank=ns.rank, num_nodes=ns.num_nodes, sync=ns.sync,
                       grad_reduce=ns.grad_reduce, batch_size=ns.batch_size, iters=ns.iters,
-                      batch_norm=ns.batch_norm, device=ns.device, backend=ns.backend,
+                      batch_norm=ns.batch_norm, arch=ns.arch, device=ns.device, backend=ns.backend,
                       dtype=ns.dtype, lr=ns.lr, train_size=256, test_size=16, summary=False,
-                      eval=False, comm_timeout_s=60.0)
+                      eval=False, comm_timeout_s=60.0, bucket_cap_mb=ns.bucket_cap_mb,
+                      first_bucket_cap_mb=min(1.0, ns.bucket_cap_mb),
+                      grad_comm_dtype=ns.grad_comm_dtype,
+                      inline_last_bucket=(None if ns.inline_last_bucket is None
+                                          else bool(ns.inline_last_bucket)),
+                      serialize_streams=ns.serialize_streams)
     torch.set_num_threads(2)
-    device = torch.device(ns.device if ns.device != "cuda" else
-                          f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}")
+    if ns.device == "cuda":
+        index = int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count()
+        device = torch.device("cuda", index)
+        torch.cuda.set_device(device)
+    else:
+        device = torch.device("cpu")
     comm = None
     if ns.sync != "none":
-        comm = init_communicator(cfg.master_ip, cfg.rank, cfg.num_nodes, device, 60.0)
+        if device.type == "cuda":
+            comm = RcclCommunicator(cfg.master_ip, cfg.rank, cfg.num_nodes, device.index, 60.0,
+                                    transport=ns.transport)
+            torch.cuda.set_stream(torch.cuda.Stream(device=device))
+        else:
+            from support.gloo_comm import HostCommunicator
+            comm = HostCommunicator(cfg.master_ip, cfg.rank, cfg.num_nodes, 60.0)
     torch.manual_seed(cfg.seed)
     tr = Trainer(cfg, device, comm)
     train_loader, _ = tr.build_loaders()
     tr.train_epoch(train_loader, 0)
+    if comm is not None:
+        comm.guard_sync(60.0)
     sd = {k: v.float().cpu() for k, v in tr.backend.state_dict().items()}
     torch.save(sd, f"{ns.out}.rank{ns.rank}")
     if ns.report_overlap:

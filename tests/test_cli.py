@@ -30,7 +30,7 @@ def test_part3_flags_and_lines():
     assert r.returncode == 0, r.stderr
     out = r.stdout
     assert "master_ip = 127.0.0.1:29517 and nodes = 1" in out
-    assert re.search(r"^\[\d+\] world_size = 1, rank = 0, backend=gloo$", out, re.M)
+    assert re.search(r"^\[\d+\] world_size = 1, rank = 0, backend=none$", out, re.M)
     assert "Epoch 0 triggered" in out
     assert "BatchNorm2d-2" in out
     assert re.search(r"^Average execution time is : [\d.e-]+ seconds$", out, re.M)
@@ -52,3 +52,37 @@ def test_rendezvous_failure_exits_nonzero():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert r.returncode != 0
     assert "could not join the process group" in r.stderr
+
+
+def test_bench_self_launch_dry_run():
+    """`bench.py --gpus N` without a launcher environment starts its own N ranks (the parent makes
+    no GPU call, so this runs anywhere): each child must see the right rank triple and one shared
+    rendezvous address."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--dry-launch"], capture_output=True, text=True, timeout=120, cwd=ROOT,
+                       env=env)
+    assert r.returncode == 0, r.stderr
+    recs = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.strip()),
+                  key=lambda d: d["rank"])
+    assert [d["rank"] for d in recs] == [0, 1] and [d["local_rank"] for d in recs] == [0, 1]
+    assert all(d["world_size"] == 2 and d["self_launched"] for d in recs)
+    assert recs[0]["master"] == recs[1]["master"] and recs[0]["master"].startswith("127.0.0.1:")
+
+
+def test_bench_launcher_env_must_match_gpus():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--dry-launch"], capture_output=True, text=True, timeout=120, cwd=ROOT,
+                       env=env)
+    assert r.returncode != 0 and "does not match --gpus" in r.stderr
+
+
+def test_cpu_device_has_no_multi_rank_transport():
+    """The only transport is RCCL: a multi-rank run on the CPU device says so and exits non-zero."""
+    cmd = [sys.executable, os.path.join(ROOT, "part2/2b/main.py"), "--device", "cpu",
+           "--master-ip", "127.0.0.1:29519", "--rank", "0", "--num-nodes", "2", "--no-summary"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode != 0
+    assert "only transport is RCCL" in r.stderr

@@ -1,0 +1,161 @@
+"""The native engine with MORE THAN ONE RANK on a single-GPU machine.
+
+RCCL refuses two ranks on one device, so these tests run the ranks over the native loopback
+test transport (csrc/comm/loopback_comm.cpp): same C++ engine, bucket reducer, manual sync,
+event choreography and bench self-checks as an RCCL run, with only the collective calls
+themselves replaced.  Reference behaviour being checked: identical parameters on every rank
+(sanity check 2 of /root/reference/group25.pdf p3) and mean-reduced data parallelism equal
+to the single-process run of the global batch (/root/reference/part1/main.py vs part2/part3).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from distributed_machine_learning_amd.launch import launch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(__file__)
+ROOT = os.path.abspath(os.path.join(HERE, ".."))
+WORKER = os.path.join(HERE, "_sync_worker.py")
+NATIVE = ["--device", "cuda", "--backend", "native", "--dtype", "bf16", "--transport", "loopback"]
+
+
+def _run(tmp_path, tag, nproc, extra):
+    out = str(tmp_path / tag)
+    if nproc == 1:
+        rc = subprocess.call([sys.executable, WORKER, "--out", out] + NATIVE + extra, timeout=300)
+    else:
+        rc = launch(WORKER, ["--out", out] + NATIVE + extra, nproc, timeout_s=300)
+    assert rc == 0, tag
+    return [torch.load(f"{out}.rank{r}", weights_only=True) for r in range(nproc)]
+
+
+def _same(a, b):
+    return all(torch.equal(a[k], b[k]) for k in a)
+
+
+def _rel(a, b, keys=None):
+    worst = 0.0
+    for k in (keys or a):
+        if a[k].dim() < 2:
+            continue
+        d = float((a[k].double() - b[k].double()).norm() / b[k].double().norm().clamp_min(1e-12))
+        worst = max(worst, d)
+    return worst
+
+
+def test_loopback_transport_collectives():
+    rc = launch(os.path.join(HERE, "_collective_worker.py"), ["--transport", "loopback"], 3,
+                timeout_s=240)
+    assert rc == 0
+
+
+@pytest.mark.parametrize("sync", ["gather_scatter", "all_reduce", "ddp"])
+def test_two_ranks_mean_match_single_process_global_batch(tmp_path, sync):
+    single = _run(tmp_path, "single", 1, ["--sync", "none", "--batch-size", "16", "--iters", "4"])[0]
+    ranks = _run(tmp_path, sync, 2, ["--sync", sync, "--grad-reduce", "mean", "--batch-size", "8",
+                                     "--iters", "4", "--bucket-cap-mb", "4"])
+    assert _same(ranks[0], ranks[1])
+    # per-sample gradients are scaled by an exact power of two (1/8 vs 1/16), so bf16 roundings
+    # agree and only the fp32 summation order differs
+    assert _rel(ranks[0], single) < 1e-4
+
+
+def test_manual_modes_default_to_sum(tmp_path):
+    gs = _run(tmp_path, "gs", 2, ["--sync", "gather_scatter", "--iters", "2", "--batch-size", "8"])
+    ar = _run(tmp_path, "ar", 2, ["--sync", "all_reduce", "--iters", "2", "--batch-size", "8"])
+    mean = _run(tmp_path, "arm", 2, ["--sync", "all_reduce", "--grad-reduce", "mean", "--iters", "2",
+                                     "--batch-size", "8"])
+    assert _same(gs[0], gs[1]) and _same(ar[0], ar[1])
+    assert _rel(gs[0], ar[0]) < 1e-6            # same sums, formed in the same rank order
+    assert _rel(mean[0], ar[0]) > 1e-4          # SUM is not MEAN
+
+
+def test_ddp_batchnorm_two_ranks_overlap_variants_agree_bitwise(tmp_path):
+    """Buckets leaving from the side stream, the in-line last bucket and the fully serialized
+    debug schedule must give the same bits on every rank, running statistics included (they
+    ride in the first bucket from rank 0)."""
+    common = ["--sync", "ddp", "--batch-norm", "--batch-size", "8", "--iters", "4",
+              "--bucket-cap-mb", "2"]
+    base = _run(tmp_path, "ddp", 2, common)
+    inline = _run(tmp_path, "ddp_inline", 2, common + ["--inline-last-bucket", "1"])
+    serial = _run(tmp_path, "ddp_serial", 2, common + ["--serialize-streams"])
+    assert _same(base[0], base[1])
+    assert _same(inline[0], inline[1]) and _same(serial[0], serial[1])
+    assert _same(base[0], inline[0])
+    assert _same(base[0], serial[0])
+    assert any("running_mean" in k for k in base[0])
+
+
+def test_ddp_bf16_wire_two_ranks(tmp_path):
+    common = ["--sync", "ddp", "--batch-norm", "--batch-size", "8", "--iters", "3",
+              "--bucket-cap-mb", "2"]
+    f32 = _run(tmp_path, "f32", 2, common)
+    b16 = _run(tmp_path, "b16", 2, common + ["--grad-comm-dtype", "bf16"])
+    assert _same(b16[0], b16[1])
+    assert not _same(b16[0], f32[0])
+    assert _rel(b16[0], f32[0]) < 2e-2
+    # the running statistics travel as fp32 next to the bf16 gradients
+    for k in f32[0]:
+        if "running" in k:
+            assert float((b16[0][k] - f32[0][k]).abs().max()) < 1e-2
+
+
+def test_mismatched_replicas_fail_loudly(tmp_path):
+    """Rank 1 builds a different network: the construction-time check must stop the job
+    (what DistributedDataParallel's constructor does for the reference, part3/main.py:137)."""
+    script = str(tmp_path / "odd.py")
+    with open(script, "w") as f:
+        f.write("import sys, runpy\n"
+                "if '--rank' in sys.argv and sys.argv[sys.argv.index('--rank') + 1] == '1':\n"
+                "    sys.argv += ['--arch', 'VGG13']\n"
+                f"sys.argv[0] = {WORKER!r}\n"
+                f"runpy.run_path({WORKER!r}, run_name='__main__')\n")
+    out = str(tmp_path / "odd")
+    rc = launch(script, ["--out", out] + NATIVE + ["--sync", "all_reduce", "--iters", "1"], 2,
+                timeout_s=240)
+    assert rc != 0
+    assert not os.path.exists(out + ".rank0")
+
+
+def _bench(args, timeout=420):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args,
+                         capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["part2a", "part2b", "part3"])
+def test_bench_self_launches_two_ranks_and_proves_it(mode):
+    rec = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--windows", "2", "--mode", mode,
+                  "--batch-size", "32", "--transport", "loopback"])
+    assert rec["n_gpus"] == 2 and rec["rccl_nranks"] == 2 and rec["transport"] == "loopback"
+    assert rec["params_in_sync"] is True
+    assert len(rec["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in rec["per_rank_ms_per_step"])
+    assert rec["ms_per_step"] == pytest.approx(max(rec["per_rank_ms_per_step"]), rel=1e-3)
+    assert rec["config"]["global_batch"] == 64 and rec["config"]["parallelism"] == "dp2"
+    assert rec["config"]["overlap"] is not None and rec["config"]["overlap"]["comm_only_ms"] > 0
+    assert rec["windows"]["n"] == 2
+    plan = rec["config"]["sync_plan"]
+    assert plan["mode"] == {"part2a": "gather_scatter", "part2b": "all_reduce", "part3": "ddp"}[mode]
+    if mode == "part3":
+        assert len(plan["buckets_mb"]) >= 3 and plan["inline_last_bucket"] is False
+
+
+def test_bench_one_rank_rccl_record_fields():
+    rec = _bench(["--steps", "5", "--warmup", "2", "--force-comm", "--report-overlap"])
+    assert rec["rccl_nranks"] == 1 and rec["transport"] == "rccl"
+    assert rec["params_in_sync"] is True and len(rec["per_rank_ms_per_step"]) == 1
+    assert rec["config"]["overlap"] is not None
+    assert rec["windows"]["min_ms_per_step"] <= rec["windows"]["median_ms_per_step"]
+    assert rec["config"]["sync_plan"]["inline_last_bucket"] is True
