@@ -8,7 +8,10 @@
 // reply = status:u8 (0 ok, 1 timeout), vlen:u32, value.  Ops: 1 SET, 2 GET (blocks on the
 // server until the key exists), 3 ADD (value = i64 delta, reply = i64 new value).
 // The server is a single poll() loop; blocked GETs are parked and answered by the SET
-// that creates their key.
+// that creates their key.  It is a rendezvous helper, not a database: keys and values are
+// capped at 64 KiB (a connection that announces more is dropped), replies are bounded by a
+// send time-out so one stalled client cannot freeze the loop, and the listener binds the
+// --master-ip host when that is an address of this machine.
 #include <arpa/inet.h>
 #include <errno.h>
 #include <netdb.h>
@@ -68,6 +71,8 @@ bool recv_all(int fd, void* buf, size_t n, double timeout_s) {
     return true;
 }
 
+constexpr uint32_t kMaxField = 64u << 10;      // key / value size cap, bytes
+
 struct Conn {
     int fd;
     std::string inbuf;
@@ -90,6 +95,7 @@ TcpStore::TcpStore(const std::string& host, int port, bool is_server, int world_
                    double timeout_s)
     : host_(host), port_(port), is_server_(is_server), world_size_(world_size),
       timeout_s_(timeout_s) {
+    bool bound_to_host = false;
     if (is_server_) {
         listen_fd_ = ::socket(AF_INET, SOCK_STREAM, 0);
         if (listen_fd_ < 0) throw std::runtime_error("TcpStore: socket() failed");
@@ -98,9 +104,15 @@ TcpStore::TcpStore(const std::string& host, int port, bool is_server, int world_
         struct sockaddr_in addr;
         memset(&addr, 0, sizeof(addr));
         addr.sin_family = AF_INET;
-        addr.sin_addr.s_addr = htonl(INADDR_ANY);
         addr.sin_port = htons((uint16_t)port_);
-        if (::bind(listen_fd_, (struct sockaddr*)&addr, sizeof(addr)) != 0) {
+        // listen on the rendezvous address itself when it is a local IPv4 address (the
+        // reference's default 127.0.1.1, or this node's address), on every interface otherwise
+        bool bound = false;
+        if (::inet_pton(AF_INET, host_.c_str(), &addr.sin_addr) == 1)
+            bound = ::bind(listen_fd_, (struct sockaddr*)&addr, sizeof(addr)) == 0;
+        bound_to_host = bound;
+        if (!bound) addr.sin_addr.s_addr = htonl(INADDR_ANY);
+        if (!bound && ::bind(listen_fd_, (struct sockaddr*)&addr, sizeof(addr)) != 0) {
             ::close(listen_fd_);
             throw std::runtime_error("TcpStore: cannot bind port " + std::to_string(port_) + ": " +
                                      strerror(errno));
@@ -118,7 +130,7 @@ TcpStore::TcpStore(const std::string& host, int port, bool is_server, int world_
     memset(&hints, 0, sizeof(hints));
     hints.ai_family = AF_INET;
     hints.ai_socktype = SOCK_STREAM;
-    const std::string target = is_server_ ? std::string("127.0.0.1") : host_;
+    const std::string target = (is_server_ && !bound_to_host) ? std::string("127.0.0.1") : host_;
     const std::string port_s = std::to_string(port_);
     if (::getaddrinfo(target.c_str(), port_s.c_str(), &hints, &res) != 0 || !res) {
         stop_ = true;
@@ -175,6 +187,8 @@ void TcpStore::serve() {
             if (fd >= 0) {
                 int one = 1;
                 ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+                struct timeval tv = {2, 0};     // a reply never blocks the loop for longer
+                ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
                 Conn c;
                 c.fd = fd;
                 conns.push_back(c);
@@ -199,9 +213,20 @@ void TcpStore::serve() {
                 const uint8_t op = (uint8_t)c.inbuf[0];
                 uint32_t klen;
                 memcpy(&klen, c.inbuf.data() + 1, 4);
-                if (c.inbuf.size() < 5 + (size_t)klen + 4) break;
-                uint32_t vlen;
-                memcpy(&vlen, c.inbuf.data() + 5 + klen, 4);
+                bool oversize = klen > kMaxField;
+                uint32_t vlen = 0;
+                if (!oversize) {
+                    if (c.inbuf.size() < 5 + (size_t)klen + 4) break;
+                    memcpy(&vlen, c.inbuf.data() + 5 + klen, 4);
+                    oversize = vlen > kMaxField;
+                }
+                if (oversize) {      // not one of ours: drop the connection, keep serving
+                    reply(c.fd, 1, "");
+                    ::close(c.fd);
+                    c.fd = -1;
+                    live_clients_.fetch_sub(1);
+                    break;
+                }
                 const size_t need = 5 + (size_t)klen + 4 + vlen;
                 if (c.inbuf.size() < need) break;
                 const std::string key = c.inbuf.substr(5, klen);

@@ -103,7 +103,8 @@ def test_ddp_bf16_wire_two_ranks(tmp_path):
     # the running statistics travel as fp32 next to the bf16 gradients
     for k in f32[0]:
         if "running" in k:
-            assert float((b16[0][k] - f32[0][k]).abs().max()) < 1e-2
+            d = (b16[0][k].double() - f32[0][k].double()).norm() / f32[0][k].double().norm()
+            assert float(d) < 2e-2, k
 
 
 def test_mismatched_replicas_fail_loudly(tmp_path):

@@ -45,6 +45,31 @@ def test_tcp_store_get_times_out_cleanly():
         server.get("never-set")
 
 
+def test_tcp_store_drops_oversize_requests_and_keeps_serving():
+    """A peer that announces a 3 GiB key is cut off; the ranks' own traffic is unaffected."""
+    import socket
+    import struct
+    C = native.lib()
+    server = C.TcpStore("127.0.0.1", 0, True, 1, 5.0)
+    with socket.create_connection(("127.0.0.1", server.port), timeout=5) as s:
+        s.sendall(b"\x01" + struct.pack("<I", 3 << 30))
+        s.settimeout(5)
+        data = s.recv(16)
+        assert data[:1] == b"\x01" or data == b""        # rejected (status 1) or closed
+        assert s.recv(16) == b""                          # and the connection is gone
+    server.set("k", b"v")
+    assert server.get("k") == b"v"
+    with pytest.raises(RuntimeError):
+        server.set("big", b"x" * (70 << 10))              # over the 64 KiB value cap
+
+
+def test_build_id_matches_sources():
+    """The library carries the hash of the sources it was built from; ops.native refuses a stale
+    one (a checkout with fresh file times cannot hide it)."""
+    from distributed_machine_learning_amd.buildinfo import tree_hash
+    assert native.lib().build_id == tree_hash()
+
+
 def test_tcp_store_connect_timeout():
     C = native.lib()
     with pytest.raises(RuntimeError, match="timed out"):
