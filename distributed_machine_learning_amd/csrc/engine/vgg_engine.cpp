@@ -40,71 +40,92 @@ void check_hip(hipError_t e, const char* what) {
 
 }  // namespace
 
-VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_norm,
-                     int num_classes)
-    : max_batch_(max_batch), num_classes_(num_classes), bn_(batch_norm) {
-    if (max_batch <= 0) throw std::invalid_argument("VggEngine: batch must be positive");
+ParamLayout plan_parameters(const std::vector<int>& widths, bool batch_norm, int num_classes) {
     if (num_classes < 1 || num_classes > 16)
         throw std::invalid_argument("VggEngine: num_classes must be in [1,16]");
+    ParamLayout out;
     int cin = 3, hw = 32, module_index = 0;
     size_t p = 0, b = 0;
     for (size_t i = 0; i < widths.size(); ++i) {
         const int w = widths[i];
         if (w < 0) {
-            if (convs_.empty() || convs_.back().pool_after || hw < 2)
+            if (out.convs.empty() || out.convs.back().pool_after || hw < 2)
                 throw std::invalid_argument("VggEngine: misplaced pool in width table");
-            convs_.back().pool_after = true;
+            out.convs.back().pool_after = true;
             hw /= 2;
             ++module_index;
             continue;
         }
         if (w % 64) throw std::invalid_argument("VggEngine: channel widths must be multiples of 64");
-        if (convs_.empty() && w != 64)
+        if (out.convs.empty() && w != 64)
             throw std::invalid_argument("VggEngine: the first conv must have 64 channels");
-        Conv c;
+        ParamLayout::Conv c;
         c.cin = cin; c.cout = w; c.hw = hw; c.pool_after = false;
-        c.gamma_off = c.beta_off = c.rm_off = c.rv_off = c.save_off = 0;
-        const int layer = (int)convs_.size();
+        c.gamma_off = c.beta_off = c.rm_off = c.rv_off = 0;
+        const int layer = (int)out.convs.size();
         const std::string key = "layers." + std::to_string(module_index);
         c.w_off = p;
-        slots_.push_back({key + ".weight", p, (size_t)w * 9 * cin, {w, 3, 3, cin}, layer});
+        out.slots.push_back({key + ".weight", p, (size_t)w * 9 * cin, {w, 3, 3, cin}, layer});
         p = align_up(p + (size_t)w * 9 * cin);
         c.b_off = p;
-        slots_.push_back({key + ".bias", p, (size_t)w, {w}, layer});
+        out.slots.push_back({key + ".bias", p, (size_t)w, {w}, layer});
         p = align_up(p + w);
         ++module_index;
-        if (bn_) {
+        if (batch_norm) {
             const std::string bkey = "layers." + std::to_string(module_index);
             c.gamma_off = p;
-            slots_.push_back({bkey + ".weight", p, (size_t)w, {w}, layer});
+            out.slots.push_back({bkey + ".weight", p, (size_t)w, {w}, layer});
             p = align_up(p + w);
             c.beta_off = p;
-            slots_.push_back({bkey + ".bias", p, (size_t)w, {w}, layer});
+            out.slots.push_back({bkey + ".bias", p, (size_t)w, {w}, layer});
             p = align_up(p + w);
             c.rm_off = b;
-            bn_slots_.push_back({bkey + ".running_mean", b, (size_t)w, {w}, layer});
+            out.bn_slots.push_back({bkey + ".running_mean", b, (size_t)w, {w}, layer});
             b = align_up(b + w);
             c.rv_off = b;
-            bn_slots_.push_back({bkey + ".running_var", b, (size_t)w, {w}, layer});
+            out.bn_slots.push_back({bkey + ".running_var", b, (size_t)w, {w}, layer});
             b = align_up(b + w);
             ++module_index;
         }
         ++module_index;   // the ReLU
-        convs_.push_back(c);
+        out.convs.push_back(c);
         cin = w;
     }
-    if (convs_.empty()) throw std::invalid_argument("VggEngine: empty width table");
-    fc_in_ = cin * hw * hw;
+    if (out.convs.empty()) throw std::invalid_argument("VggEngine: empty width table");
+    out.fc_in = cin * hw * hw;
     if (hw != 1) throw std::invalid_argument("VggEngine: the feature map must be 1x1 at the classifier");
-    const int fc_layer = (int)convs_.size();
-    fcw_off_ = p;
-    slots_.push_back({"fc1.weight", p, (size_t)num_classes * fc_in_, {num_classes, fc_in_}, fc_layer});
-    p = align_up(p + (size_t)num_classes * fc_in_);
-    fcb_off_ = p;
-    slots_.push_back({"fc1.bias", p, (size_t)num_classes, {num_classes}, fc_layer});
+    const int fc_layer = (int)out.convs.size();
+    out.fcw_off = p;
+    out.slots.push_back({"fc1.weight", p, (size_t)num_classes * out.fc_in, {num_classes, out.fc_in},
+                         fc_layer});
+    p = align_up(p + (size_t)num_classes * out.fc_in);
+    out.fcb_off = p;
+    out.slots.push_back({"fc1.bias", p, (size_t)num_classes, {num_classes}, fc_layer});
     p = align_up(p + num_classes);
-    param_elems_ = p;
-    bn_elems_ = b;
+    out.param_elems = p;
+    out.bn_elems = b;
+    return out;
+}
+
+VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_norm,
+                     int num_classes)
+    : max_batch_(max_batch), num_classes_(num_classes), bn_(batch_norm) {
+    if (max_batch <= 0) throw std::invalid_argument("VggEngine: batch must be positive");
+    const ParamLayout lay = plan_parameters(widths, batch_norm, num_classes);
+    for (const ParamLayout::Conv& l : lay.convs) {
+        Conv c;
+        c.cin = l.cin; c.cout = l.cout; c.hw = l.hw; c.pool_after = l.pool_after;
+        c.w_off = l.w_off; c.b_off = l.b_off; c.gamma_off = l.gamma_off; c.beta_off = l.beta_off;
+        c.rm_off = l.rm_off; c.rv_off = l.rv_off; c.save_off = 0;
+        convs_.push_back(c);
+    }
+    slots_ = lay.slots;
+    bn_slots_ = lay.bn_slots;
+    fc_in_ = lay.fc_in;
+    fcw_off_ = lay.fcw_off;
+    fcb_off_ = lay.fcb_off;
+    param_elems_ = lay.param_elems;
+    bn_elems_ = lay.bn_elems;
 
     // ---- bf16 arena
     size_t a = 0;

@@ -1,0 +1,348 @@
+// VggEngineF32: the training step at the reference's precision.
+//
+// The reference trains in fp32 end to end (/root/reference/part1/main.py:15-16,38-46): fp32
+// weights, activations, gradients and optimizer state.  This engine runs the same fixed layer
+// plan as VggEngine with every tensor in fp32 - activations NHWC fp32, the master weights used
+// directly by the kernels (no low-precision shadow), convolutions on the fp32-input matrix
+// instruction (exact fp32 products and sums).  At 1/16 of the bf16 matrix rate the step is
+// bound by the convolutions' arithmetic, so the schedule is the plain one: a single stream,
+// unfused BatchNorm / pool kernels (the templates VggEngine's kernels are instantiated from),
+// bucket hooks between layers.
+//
+//   forward : conv(+bias[+ReLU]) -> [BatchNorm(train stats)+ReLU] -> [max-pool]   per layer
+//   loss    : classifier rows + batch reductions (logits, loss, dlogits, dx, dW, db)
+//   backward: [pool bwd] -> [BatchNorm+ReLU bwd] -> bias grad -> wgrad (+ slab sum) -> dgrad
+//   update  : reducer wait / manual sync -> fused SGD -> backward-data weight repacks
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <stdexcept>
+
+#include "dml_engine.h"
+#include "dml_kernels.h"
+#include "dml_trace.h"
+
+namespace py = pybind11;
+
+namespace dml {
+
+namespace {
+constexpr size_t kAlign = 64;
+size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+void check_hip(hipError_t e, const char* what) {
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string("HIP ") + what + " failed: " + hipGetErrorString(e));
+}
+}  // namespace
+
+VggEngineF32::VggEngineF32(const std::vector<int>& widths, int max_batch, bool batch_norm,
+                           int num_classes)
+    : max_batch_(max_batch), num_classes_(num_classes), bn_(batch_norm) {
+    if (max_batch <= 0) throw std::invalid_argument("VggEngineF32: batch must be positive");
+    lay_ = plan_parameters(widths, batch_norm, num_classes);
+    const size_t B = (size_t)max_batch_;
+    size_t a = 0, max_act = 0;
+    for (size_t i = 0; i < lay_.convs.size(); ++i) {
+        const ParamLayout::Conv& c = lay_.convs[i];
+        if (i > 0 && c.cout % 128)
+            throw std::invalid_argument("VggEngineF32: layers after the first need a multiple of "
+                                        "128 output channels");
+        Buffers b;
+        const size_t act = B * c.hw * c.hw * c.cout;
+        max_act = act > max_act ? act : max_act;
+        b.wd_off = a;
+        if (i > 0) a = align_up(a + (size_t)c.cout * 9 * c.cin);
+        b.pre_off = a;
+        if (bn_) a = align_up(a + act);
+        b.out_off = a; a = align_up(a + act);
+        b.pool_off = a;
+        if (c.pool_after) a = align_up(a + act / 4);
+        b.gout_off = a; a = align_up(a + act);
+        buf_.push_back(b);
+    }
+    ta_off_ = a; a = align_up(a + max_act);
+    tb_off_ = a; a = align_up(a + max_act);
+    arena_elems_ = a;
+
+    size_t w = 0;
+    logits_off_ = w; w = align_up(w + B * 16);
+    loss_off_ = w;   w = align_up(w + 64);
+    stats_off_ = w;  w = align_up(w + bn_workspace_elems());
+    fc_ws_off_ = w;  w = align_up(w + fc_train_workspace_elems(max_batch_, lay_.fc_in, num_classes_));
+    c1_ws_off_ = w;  w = align_up(w + conv1_wgrad_f32_workspace_elems(max_batch_));
+    for (size_t i = 0; i < lay_.convs.size(); ++i) {
+        const ParamLayout::Conv& c = lay_.convs[i];
+        buf_[i].save_off = w;
+        if (bn_) w = align_up(w + 2 * (size_t)c.cout);
+        buf_[i].wslab_off = w;
+        if (i > 0) {
+            const int splits = conv3x3_wgrad_f32_splits({max_batch_, c.hw, c.cin, c.cout});
+            if (splits > 1) w = align_up(w + (size_t)splits * c.cout * 9 * c.cin);
+        }
+    }
+    ws_elems_ = w;
+    buckets_by_layer_.assign(lay_.convs.size() + 1, {});
+}
+
+void VggEngineF32::bind(float* params, float* grads, float* momentum, float* bn_buffers,
+                        float* arena, float* workspace) {
+    if (!params || !grads || !momentum || !arena || !workspace || (bn_ && !bn_buffers))
+        throw std::invalid_argument("VggEngineF32::bind: null buffer");
+    params_ = params; grads_ = grads; mom_ = momentum; bnbuf_ = bn_buffers;
+    arena_ = arena; ws_ = workspace;
+}
+
+void VggEngineF32::set_reducer(BucketReducer* reducer, const std::vector<BucketRange>& buckets) {
+    reducer_ = reducer;
+    buckets_by_layer_.assign(lay_.convs.size() + 1, {});
+    if (!reducer) return;
+    if ((int)buckets.size() != reducer->num_buckets())
+        throw std::invalid_argument("VggEngineF32::set_reducer: bucket count mismatch");
+    for (size_t b = 0; b < buckets.size(); ++b) {
+        const int lo = buckets[b].lo;
+        if (lo < 0 || lo >= (int)lay_.slots.size())
+            throw std::invalid_argument("VggEngineF32::set_reducer: bucket range outside the slots");
+        // complete once the layer owning its first (earliest) slot has run backward
+        buckets_by_layer_[lay_.slots[lo].layer].push_back((int)b);
+    }
+}
+
+void VggEngineF32::fire_buckets(int layer, hipStream_t stream) {
+    if (!reducer_ || buckets_by_layer_[layer].empty()) return;
+    TraceRange range("backward/buckets");
+    flush_sums(stream);
+    for (int b : buckets_by_layer_[layer]) reducer_->bucket_ready(b, stream);
+}
+
+void VggEngineF32::flush_sums(hipStream_t stream) {
+    if (sums_.n == 0) return;
+    sum_slabs_batch(ws_, grads_, sums_, stream);
+    sums_.n = 0;
+}
+
+void VggEngineF32::refresh_weights(hipStream_t stream) {
+    if (!params_) throw std::logic_error("VggEngineF32: bind() first");
+    for (size_t i = 1; i < lay_.convs.size(); ++i) {
+        const ParamLayout::Conv& c = lay_.convs[i];
+        repack_dgrad_weights_f32(params_ + c.w_off, arena_ + buf_[i].wd_off, c.cout, c.cin, stream);
+    }
+}
+
+std::vector<std::vector<long long>> VggEngineF32::layer_table() const {
+    std::vector<std::vector<long long>> out;
+    for (size_t i = 0; i < lay_.convs.size(); ++i) {
+        const ParamLayout::Conv& c = lay_.convs[i];
+        out.push_back({c.cin, c.cout, c.hw, c.pool_after ? 1 : 0, (long long)buf_[i].pre_off,
+                       (long long)buf_[i].out_off, (long long)buf_[i].pool_off,
+                       (long long)buf_[i].gout_off});
+    }
+    return out;
+}
+
+std::vector<long long> VggEngineF32::bn_save_offsets() const {
+    std::vector<long long> out;
+    for (const Buffers& b : buf_) out.push_back(bn_ ? (long long)b.save_off : -1);
+    return out;
+}
+
+void VggEngineF32::forward(const float* x, int batch, bool training, hipStream_t stream) {
+    if (!params_) throw std::logic_error("VggEngineF32: bind() first");
+    if (batch <= 0 || batch > max_batch_) throw std::invalid_argument("VggEngineF32: bad batch size");
+    TraceRange range(training ? "forward" : "forward(eval)");
+    const float* in = x;
+    for (size_t i = 0; i < lay_.convs.size(); ++i) {
+        const ParamLayout::Conv& c = lay_.convs[i];
+        const Buffers& b = buf_[i];
+        float* dst = arena_ + (bn_ ? b.pre_off : b.out_off);
+        if (i == 0)
+            conv1_fprop_f32(in, params_ + c.w_off, params_ + c.b_off, dst, batch, !bn_, stream);
+        else
+            conv3x3_igemm_f32(in, params_ + c.w_off, dst, params_ + c.b_off, nullptr,
+                              {batch, c.hw, c.cin, c.cout}, bn_ ? EPI_BIAS : EPI_BIAS_RELU, stream);
+        if (bn_) {
+            const int rows = batch * c.hw * c.hw;
+            if (training)
+                bn_relu_fwd_train(dst, arena_ + b.out_off, params_ + c.gamma_off,
+                                  params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off,
+                                  ws_ + b.save_off, ws_ + b.save_off + c.cout, ws_ + stats_off_,
+                                  rows, c.cout, 0.1f, 1e-5f, stream);
+            else
+                bn_relu_fwd_eval(dst, arena_ + b.out_off, params_ + c.gamma_off,
+                                 params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off, rows,
+                                 c.cout, 1e-5f, stream);
+        }
+        in = arena_ + b.out_off;
+        if (c.pool_after) {
+            maxpool2x2_fwd(in, arena_ + b.pool_off, batch, c.hw, c.cout, stream);
+            in = arena_ + b.pool_off;
+        }
+    }
+    if (!training)
+        linear_fwd(in, params_ + lay_.fcw_off, params_ + lay_.fcb_off, ws_ + logits_off_, batch,
+                   lay_.fc_in, num_classes_, stream);
+    if (training && bn_) ++bn_steps_;
+}
+
+void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hipStream_t stream) {
+    TraceRange range("backward");
+    const int nconv = (int)lay_.convs.size();
+    sums_.n = 0;
+    float* ta = arena_ + ta_off_;
+    float* tb = arena_ + tb_off_;
+    // where the gradient arriving at layer i is written: straight into the layer's own buffer
+    // when it already is dL/d(conv output) (no BatchNorm, no pool: the producer masks with the
+    // layer's ReLU output), else the transit buffer
+    auto direct = [&](int i) { return !bn_ && !lay_.convs[i].pool_after; };
+    auto arriving = [&](int i) { return direct(i) ? arena_ + buf_[i].gout_off : ta; };
+
+    const ParamLayout::Conv& last = lay_.convs[nconv - 1];
+    const float* fc_in = arena_ + (last.pool_after ? buf_[nconv - 1].pool_off : buf_[nconv - 1].out_off);
+    float* fc_dx = direct(nconv - 1) ? tb : ta;
+    fc_train_rows(fc_in, params_ + lay_.fcw_off, params_ + lay_.fcb_off, target, ws_ + logits_off_,
+                  fc_dx, ws_ + fc_ws_off_, batch, lay_.fc_in, num_classes_, stream);
+    fc_train_grads(fc_in, ws_ + fc_ws_off_, ws_ + loss_off_, nullptr, grads_ + lay_.fcw_off,
+                   grads_ + lay_.fcb_off, batch, lay_.fc_in, num_classes_, stream);
+    if (direct(nconv - 1))      // a classifier straight behind an un-pooled ReLU layer
+        relu_mask_f32(tb, arena_ + buf_[nconv - 1].out_off, arena_ + buf_[nconv - 1].gout_off,
+                      (size_t)batch * last.hw * last.hw * last.cout, stream);
+    fire_buckets(nconv, stream);
+
+    for (int i = nconv - 1; i >= 0; --i) {
+        const ParamLayout::Conv& c = lay_.convs[i];
+        const Buffers& b = buf_[i];
+        const int rows = batch * c.hw * c.hw;
+        float* g = arena_ + b.gout_off;             // dL/d(conv output)
+        float* src = arriving(i);
+        if (c.pool_after) {
+            // without BatchNorm the ReLU mask rides in the pool's routing (out is post-ReLU)
+            float* dst = bn_ ? tb : g;
+            maxpool2x2_bwd(arena_ + b.out_off, src, dst, batch, c.hw, c.cout, !bn_, stream);
+            src = dst;
+        }
+        if (bn_)
+            bn_relu_bwd(arena_ + b.pre_off, src, g, params_ + c.gamma_off, params_ + c.beta_off,
+                        ws_ + b.save_off, ws_ + b.save_off + c.cout, grads_ + c.gamma_off,
+                        grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream);
+        if (i == 0) {
+            // Conv bias gradient under BatchNorm: exactly zero in exact arithmetic (the
+            // normalisation removes any per-channel offset), left at the buffer's zero.
+            conv1_wgrad_f32(x, g, grads_ + c.w_off, bn_ ? nullptr : grads_ + c.b_off, batch,
+                            ws_ + c1_ws_off_, stream);
+        } else {
+            const ParamLayout::Conv& prev = lay_.convs[i - 1];
+            const float* in = arena_ + (prev.pool_after ? buf_[i - 1].pool_off : buf_[i - 1].out_off);
+            if (!bn_) column_sum(g, grads_ + c.b_off, rows, c.cout, ws_ + stats_off_, stream);
+            const ConvShape s = {batch, c.hw, c.cin, c.cout};
+            conv3x3_wgrad_f32(in, g, grads_ + c.w_off, s, ws_ + b.wslab_off, stream);
+            const int splits = conv3x3_wgrad_f32_splits(s);
+            if (splits > 1) {
+                if (sums_.n == SlabSumJobs::kMax) flush_sums(stream);
+                const int j = sums_.n++;
+                sums_.src_off[j] = b.wslab_off;
+                sums_.dst_off[j] = c.w_off;
+                sums_.count[j] = (size_t)c.cout * 9 * c.cin;
+                sums_.splits[j] = splits;
+            }
+            // input gradient; the producer's ReLU is folded in when nothing sits in between
+            const bool fold = direct(i - 1);
+            conv3x3_igemm_f32(g, arena_ + b.wd_off, arriving(i - 1), nullptr,
+                              fold ? arena_ + buf_[i - 1].out_off : nullptr,
+                              {batch, c.hw, c.cout, c.cin}, fold ? EPI_MASK : EPI_NONE, stream);
+        }
+        fire_buckets(i, stream);
+    }
+    flush_sums(stream);
+}
+
+void VggEngineF32::forward_backward(const float* x, const int64_t* target, int batch,
+                                    hipStream_t stream) {
+    if (!params_) throw std::logic_error("VggEngineF32: bind() first");
+    if (reducer_) {
+        reducer_->begin_step();
+        reducer_->apply_buffers(stream);        // running statistics := rank 0's
+    }
+    forward(x, batch, true, stream);
+    if (reducer_ && bn_) reducer_->buffers_updated(stream);
+    backward(x, target, batch, stream);
+}
+
+void VggEngineF32::optimizer_step(float lr, float momentum, float weight_decay, float grad_scale,
+                                  hipStream_t stream) {
+    TraceRange range("optimizer");
+    if (reducer_) reducer_->wait_all(stream);
+    sgd_momentum(params_, grads_, mom_, nullptr, lay_.param_elems, lr, momentum, weight_decay,
+                 grad_scale, false, stream);
+    const float* bsrc = nullptr; float* bdst = nullptr; size_t bn = 0;
+    if (reducer_ && reducer_->take_pending_buffers(&bsrc, &bdst, &bn))
+        check_hip(hipMemcpyAsync(bdst, bsrc, bn * sizeof(float), hipMemcpyDeviceToDevice, stream),
+                  "hipMemcpyAsync(buffers)");
+    refresh_weights(stream);
+}
+
+void VggEngineF32::train_step(const float* x, const int64_t* target, int batch, float lr,
+                              float momentum, float weight_decay, float grad_scale,
+                              hipStream_t stream) {
+    TraceRange range("train_step");
+    forward_backward(x, target, batch, stream);
+    if (manual_sync_) {
+        TraceRange sync(manual_sync_->mode() == ManualSync::ALL_REDUCE ? "sync/all_reduce"
+                                                                        : "sync/gather_scatter");
+        manual_sync_->run(stream);
+    }
+    optimizer_step(lr, momentum, weight_decay, grad_scale, stream);
+}
+
+void VggEngineF32::eval_step(const float* x, const int64_t* target, int batch, hipStream_t stream) {
+    forward(x, batch, false, stream);
+    softmax_xent(ws_ + logits_off_, target, ws_ + loss_off_ + 1, nullptr,
+                 (int32_t*)(ws_ + loss_off_ + 2), batch, num_classes_, 1.0f, stream);
+}
+
+void bind_engine_f32(py::module_& m) {
+    py::class_<VggEngineF32>(m, "VggEngineF32")
+        .def(py::init<const std::vector<int>&, int, bool, int>())
+        .def_property_readonly("param_elems", &VggEngineF32::param_elems)
+        .def_property_readonly("bn_elems", &VggEngineF32::bn_elems)
+        .def_property_readonly("arena_elems", &VggEngineF32::arena_elems)
+        .def_property_readonly("workspace_elems", &VggEngineF32::workspace_elems)
+        .def_property_readonly("param_slots", &VggEngineF32::param_slots)
+        .def_property_readonly("buffer_slots", &VggEngineF32::buffer_slots)
+        .def_property_readonly("num_conv", &VggEngineF32::num_conv)
+        .def_property_readonly("layer_table", &VggEngineF32::layer_table)
+        .def_property_readonly("bn_save_offsets", &VggEngineF32::bn_save_offsets)
+        .def_property("bn_steps", &VggEngineF32::bn_steps, &VggEngineF32::set_bn_steps)
+        .def_property_readonly("logits_offset", &VggEngineF32::logits_offset)
+        .def_property_readonly("loss_offset", &VggEngineF32::loss_offset)
+        .def("bind", [](VggEngineF32& e, uintptr_t p, uintptr_t g, uintptr_t mo, uintptr_t bn,
+                        uintptr_t arena, uintptr_t ws) {
+            e.bind((float*)p, (float*)g, (float*)mo, (float*)bn, (float*)arena, (float*)ws);
+        })
+        .def("set_reducer", [](VggEngineF32& e, BucketReducer* r,
+                               std::vector<std::pair<int, int>> buckets) {
+            std::vector<BucketRange> b;
+            for (auto& p : buckets) b.push_back({p.first, p.second});
+            e.set_reducer(r, b);
+        }, py::keep_alive<1, 2>())
+        .def("set_manual_sync", [](VggEngineF32& e, ManualSync* m) { e.set_manual_sync(m); },
+             py::keep_alive<1, 2>())
+        .def("refresh_weights", [](VggEngineF32& e, uintptr_t s) { e.refresh_weights((hipStream_t)s); })
+        .def("forward", [](VggEngineF32& e, uintptr_t x, int batch, bool training, uintptr_t s) {
+            e.forward((const float*)x, batch, training, (hipStream_t)s);
+        })
+        .def("forward_backward", [](VggEngineF32& e, uintptr_t x, uintptr_t t, int batch, uintptr_t s) {
+            e.forward_backward((const float*)x, (const int64_t*)t, batch, (hipStream_t)s);
+        })
+        .def("optimizer_step", [](VggEngineF32& e, float lr, float mu, float wd, float gs, uintptr_t s) {
+            e.optimizer_step(lr, mu, wd, gs, (hipStream_t)s);
+        })
+        .def("train_step", [](VggEngineF32& e, uintptr_t x, uintptr_t t, int batch, float lr, float mu,
+                              float wd, float gs, uintptr_t s) {
+            e.train_step((const float*)x, (const int64_t*)t, batch, lr, mu, wd, gs, (hipStream_t)s);
+        })
+        .def("eval_step", [](VggEngineF32& e, uintptr_t x, uintptr_t t, int batch, uintptr_t s) {
+            e.eval_step((const float*)x, (const int64_t*)t, batch, (hipStream_t)s);
+        });
+}
+
+}  // namespace dml

@@ -16,7 +16,8 @@
 namespace dml {
 
 constexpr int kColReduceSlabFloats = 131072;                       // 512 KiB
-constexpr int kColReduceWsFloats = kColReduceSlabFloats;
+constexpr int kColReduceShiftFloats = 2048;    // one per-column vector behind the slab
+constexpr int kColReduceWsFloats = kColReduceSlabFloats + kColReduceShiftFloats;
 
 struct ColReducePlan {
     int blocks, rows_per_block;

@@ -56,6 +56,45 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return v;
 }
 
+// Eight consecutive activation elements <-> eight floats, for both storage types the kernels
+// are instantiated with: uint16_t = bf16 bit patterns (one 16-byte vector), float (two).
+__device__ __forceinline__ void load8(const uint16_t* p, float (&f)[8]) {
+    unpack8(*(const uint4*)p, f);
+}
+__device__ __forceinline__ void load8(const float* p, float (&f)[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void store8(uint16_t* p, const float (&f)[8]) {
+    *(uint4*)p = pack8(f);
+}
+__device__ __forceinline__ void store8(float* p, const float (&f)[8]) {
+    *(float4*)p = float4{f[0], f[1], f[2], f[3]};
+    *(float4*)(p + 4) = float4{f[4], f[5], f[6], f[7]};
+}
+// the same eight elements moved without conversion
+template <typename T> struct Raw8;
+template <> struct Raw8<uint16_t> { uint4 v = {0, 0, 0, 0}; };
+template <> struct Raw8<float> { float4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f}; };
+__device__ __forceinline__ Raw8<uint16_t> load_raw8(const uint16_t* p) {
+    Raw8<uint16_t> r;
+    r.v = *(const uint4*)p;
+    return r;
+}
+__device__ __forceinline__ Raw8<float> load_raw8(const float* p) {
+    Raw8<float> r;
+    r.a = *(const float4*)p;
+    r.b = *(const float4*)(p + 4);
+    return r;
+}
+__device__ __forceinline__ void store_raw8(uint16_t* p, const Raw8<uint16_t>& r) { *(uint4*)p = r.v; }
+__device__ __forceinline__ void store_raw8(float* p, const Raw8<float>& r) {
+    *(float4*)p = r.a;
+    *(float4*)(p + 4) = r.b;
+}
+__device__ __forceinline__ float elem_to_float(uint16_t v) { return bf16_bits_to_float(v); }
+__device__ __forceinline__ float elem_to_float(float v) { return v; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

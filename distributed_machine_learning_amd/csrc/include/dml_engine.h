@@ -41,6 +41,22 @@ struct SlotInfo {
     int layer;                 // conv layer index, or n_conv for the classifier
 };
 
+// Parameter and buffer slots of a VGG-family network in named_parameters() order - the
+// state_dict contract of /root/reference/part1/model.py:11-46 - shared by both engines.
+struct ParamLayout {
+    struct Conv {
+        int cin, cout, hw;
+        bool pool_after;
+        size_t w_off, b_off, gamma_off, beta_off;     // flat params
+        size_t rm_off, rv_off;                        // bn_buffers
+    };
+    std::vector<Conv> convs;
+    std::vector<SlotInfo> slots, bn_slots;
+    size_t fcw_off = 0, fcb_off = 0, param_elems = 0, bn_elems = 0;
+    int fc_in = 0;
+};
+ParamLayout plan_parameters(const std::vector<int>& widths, bool batch_norm, int num_classes);
+
 class VggEngine {
   public:
     // widths: output channels per conv layer, -1 for a 2x2 max-pool (the VGG width table)
@@ -172,6 +188,68 @@ class VggEngine {
     hipGraphExec_t graph_exec_ = nullptr;
 };
 
+// The same network with every tensor in fp32 (the reference's precision); see
+// csrc/engine/vgg_engine_f32.cpp.  Buffers as for VggEngine, except that the arena is fp32 and
+// holds no weight shadow (the kernels read the master weights).
+class VggEngineF32 {
+  public:
+    VggEngineF32(const std::vector<int>& widths, int max_batch, bool batch_norm, int num_classes);
+
+    size_t param_elems() const { return lay_.param_elems; }
+    size_t bn_elems() const { return lay_.bn_elems; }
+    size_t arena_elems() const { return arena_elems_; }
+    size_t workspace_elems() const { return ws_elems_; }
+    const std::vector<SlotInfo>& param_slots() const { return lay_.slots; }
+    const std::vector<SlotInfo>& buffer_slots() const { return lay_.bn_slots; }
+    int num_conv() const { return (int)lay_.convs.size(); }
+    long long bn_steps() const { return bn_steps_; }
+    void set_bn_steps(long long v) { bn_steps_ = v; }
+    size_t logits_offset() const { return logits_off_; }
+    size_t loss_offset() const { return loss_off_; }   // [loss, eval_loss, eval_correct(int32)]
+    // per conv layer: {cin, cout, hw, pool_after, pre_off, out_off, pool_off, gout_off} (arena
+    // elements; gout = dL/d(conv output) of the last backward pass)
+    std::vector<std::vector<long long>> layer_table() const;
+    std::vector<long long> bn_save_offsets() const;
+
+    void bind(float* params, float* grads, float* momentum, float* bn_buffers, float* arena,
+              float* workspace);
+    void set_reducer(BucketReducer* reducer, const std::vector<BucketRange>& buckets);
+    void set_manual_sync(ManualSync* sync) { manual_sync_ = sync; }
+    void refresh_weights(hipStream_t stream);       // backward-data weight layouts
+    void forward(const float* x_nhwc4, int batch, bool training, hipStream_t stream);
+    void forward_backward(const float* x_nhwc4, const int64_t* target, int batch,
+                          hipStream_t stream);
+    void optimizer_step(float lr, float momentum, float weight_decay, float grad_scale,
+                        hipStream_t stream);
+    void train_step(const float* x_nhwc4, const int64_t* target, int batch, float lr,
+                    float momentum, float weight_decay, float grad_scale, hipStream_t stream);
+    void eval_step(const float* x_nhwc4, const int64_t* target, int batch, hipStream_t stream);
+
+  private:
+    struct Buffers {
+        size_t wd_off = 0, pre_off = 0, out_off = 0, pool_off = 0, gout_off = 0;   // arena
+        size_t save_off = 0, wslab_off = 0;                                        // workspace
+    };
+    void backward(const float* x, const int64_t* target, int batch, hipStream_t stream);
+    void fire_buckets(int layer, hipStream_t stream);
+    void flush_sums(hipStream_t stream);
+
+    ParamLayout lay_;
+    std::vector<Buffers> buf_;
+    int max_batch_, num_classes_;
+    bool bn_;
+    size_t arena_elems_ = 0, ws_elems_ = 0, ta_off_ = 0, tb_off_ = 0;
+    size_t logits_off_ = 0, loss_off_ = 0, stats_off_ = 0, fc_ws_off_ = 0, c1_ws_off_ = 0;
+    float *params_ = nullptr, *grads_ = nullptr, *mom_ = nullptr, *bnbuf_ = nullptr,
+          *arena_ = nullptr, *ws_ = nullptr;
+    BucketReducer* reducer_ = nullptr;
+    ManualSync* manual_sync_ = nullptr;
+    std::vector<std::vector<int>> buckets_by_layer_;
+    SlabSumJobs sums_;
+    long long bn_steps_ = 0;
+};
+
 void bind_engine(pybind11::module_& m);
+void bind_engine_f32(pybind11::module_& m);
 
 }  // namespace dml

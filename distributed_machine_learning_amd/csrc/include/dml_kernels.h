@@ -260,6 +260,63 @@ void sum_slabs(float* slabs, int world, size_t n, hipStream_t stream);
 // fill a bf16 buffer with uniform values in [-1, 1) from a counter hash (tests / benches)
 void fill_uniform_bf16(bf16_raw* out, size_t n, uint32_t seed, float scale, hipStream_t stream);
 
+// ---------------------------------------------------------------- fp32 activations
+// The reference trains in fp32 end to end (/root/reference/part1/main.py:15-16: default dtype
+// on the CPU).  The same operations on NHWC fp32 tensors, for --dtype fp32: overloads of the
+// memory-bound kernels above (instantiations of the same templates), and fp32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 products and sums) convolutions.
+void maxpool2x2_fwd(const float* x, float* y, int batch, int hw, int c, hipStream_t stream);
+void maxpool2x2_bwd(const float* x, const float* dy, float* dx, int batch, int hw, int c,
+                    bool relu_mask, hipStream_t stream);
+void column_sum(const float* x, float* out, int rows, int cols, float* ws, hipStream_t stream);
+void bn_relu_fwd_train(const float* x, float* y, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* save_mean,
+                       float* save_rstd, float* stats_ws, int rows, int c, float momentum,
+                       float eps, hipStream_t stream);
+void bn_relu_fwd_eval(const float* x, float* y, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, int rows, int c,
+                      float eps, hipStream_t stream);
+void bn_relu_bwd(const float* x, float* dy, float* dx, const float* gamma, const float* beta,
+                 const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                 float* stats_ws, int rows, int c, hipStream_t stream);
+void linear_fwd(const float* x, const float* w, const float* bias, float* logits, int batch,
+                int in_features, int out_features, hipStream_t stream);
+void fc_train_rows(const float* x, const float* w, const float* bias, const int64_t* target,
+                   float* logits, float* dx, float* ws, int batch, int in_features,
+                   int out_features, hipStream_t stream);
+void fc_train_grads(const float* x, const float* ws, float* loss, int32_t* correct, float* dw,
+                    float* db, int batch, int in_features, int out_features, hipStream_t stream);
+void augment_normalize(const uint8_t* images, const int32_t* aug, float* out, int batch,
+                       const float mean[3], const float stdv[3], hipStream_t stream);
+void nchw_to_nhwc4(const float* x, float* out, int batch, hipStream_t stream);
+
+// Implicit GEMM on fp32 NHWC tensors, same contract as conv3x3_igemm (forward with
+// w = [cout][9][cin], backward-data with w = repack_dgrad_weights_f32 and cin/cout swapped).
+// `mask` (EPI_MASK) has the output's shape.  No workspace: the reduction is never split.
+void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bias,
+                       const float* mask, ConvShape s, ConvEpilogue epi, hipStream_t stream,
+                       int force_tile = 0 /* tuning: 128 or 64 */);
+// wd[cin][8 - tap][cout] = wf[cout][tap][cin]
+void repack_dgrad_weights_f32(const float* wf, float* wd, int cout, int cin, hipStream_t stream);
+// dw[cout][9][cin] = sum_p dy[p][cout] * x[p (+) tap][cin].  The pixel range is split over
+// conv3x3_wgrad_f32_splits(s) blocks per tile; with more than one split every split stores its
+// partial result to `slab` (splits * cout*9*cin floats) and the caller sums them
+// (sum_slabs_batch), with one split `dw` is written directly.
+void conv3x3_wgrad_f32(const float* x, const float* dy, float* dw, ConvShape s, float* slab,
+                       hipStream_t stream, int force_splits = 0);
+int conv3x3_wgrad_f32_splits(ConvShape s, int force_splits = 0);
+// First layer on fp32: x [B,32,32,4] (3 channels + zero pad), w the master weights
+// [64][9][3], y = relu?(conv + bias) [B,32,32,64].
+void conv1_fprop_f32(const float* x, const float* w, const float* bias, float* y, int batch,
+                     bool relu, hipStream_t stream);
+// dW1[64][9][3] and (db != nullptr) db[64] from dy [B,32,32,64]; `ws` holds
+// conv1_wgrad_f32_workspace_elems(batch) floats of per-block partials.
+void conv1_wgrad_f32(const float* x, const float* dy, float* dw, float* db, int batch, float* ws,
+                     hipStream_t stream);
+size_t conv1_wgrad_f32_workspace_elems(int batch);
+// y = mask > 0 ? x : 0  (ReLU backward where no other kernel can fold it)
+void relu_mask_f32(const float* x, const float* mask, float* y, size_t n, hipStream_t stream);
+
 // ---- streams on hardware queues of their own (stream_probe.hip)
 // true if a kernel on `candidate` starts while a kernel on `busy` is still running
 bool streams_run_concurrently(hipStream_t busy, hipStream_t candidate);

@@ -43,16 +43,32 @@ __device__ __forceinline__ void load_consts(const float* __restrict__ p, int col
 
 
 // ----------------------------------------------------------------- forward, training
-__global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restrict__ x,
+// Sums of (x - s) and (x - s)^2 with s = the column's value in row 0: a sample of the
+// distribution, so both sums stay of the order of the spread and var = E[(x-s)^2] - E[x-s]^2
+// does not cancel when |mean| >> std (the plain E[x^2] - E[x]^2 loses log2(mean^2/var) bits).
+// Every block derives the same s; block 0 leaves it behind the slab for the fold.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x,
                                                        float* __restrict__ ws, int rows, int c,
                                                        int rows_per_block) {
     __shared__ float red[4096];
+    float s[8];
+    const int cg0 = threadIdx.x % (c / 8);
+    load8(x + cg0 * 8, s);
+    if (blockIdx.x == 0 && (int)threadIdx.x < c / 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ws[kColReduceSlabFloats + cg0 * 8 + i] = s[i];
+    }
     column_partials(
         [&](int r, int cg, float (&a)[8], float (&b)[8]) {
             float v[8];
-            unpack8(*(const uint4*)(x + (size_t)r * c + cg * 8), v);
+            load8(x + (size_t)r * c + cg * 8, v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { a[i] += v[i]; b[i] += v[i] * v[i]; }
+            for (int i = 0; i < 8; ++i) {
+                const float d = v[i] - s[i];
+                a[i] += d;
+                b[i] += d * d;
+            }
         },
         ws, rows, c, rows_per_block, red);
 }
@@ -66,7 +82,8 @@ __global__ __launch_bounds__(256) void bn_stats_finish_kernel(
         [&](int col, float s1, float s2) {
             const float m0 = s1 * inv_n;
             const float var = fmaxf(s2 * inv_n - m0 * m0, 0.f);
-            // partial sums from a conv epilogue leave the bias out: it only moves the mean
+            // the sums are of x - shift (a conv epilogue leaves the bias out, the statistics
+            // pass subtracts row 0): a shift only moves the mean
             const float mean = shift ? m0 + shift[col] : m0;
             save_mean[col] = mean;
             save_rstd[col] = rsqrtf(var + eps);
@@ -82,7 +99,8 @@ __global__ __launch_bounds__(256) void bn_stats_finish_kernel(
 namespace {
 // mean / rstd (+ running statistics) either from a pass over x or from partial sums a
 // producer kernel already left behind
-void batch_statistics(const bf16_raw* x, float* ws, int rows, int c, float* save_mean,
+template <typename T>
+void batch_statistics(const T* x, float* ws, int rows, int c, float* save_mean,
                       float* save_rstd, float* running_mean, float* running_var, float momentum,
                       float eps, const BnPartials& from, hipStream_t stream) {
     if (from.data) {
@@ -93,11 +111,11 @@ void batch_statistics(const bf16_raw* x, float* ws, int rows, int c, float* save
         return;
     }
     const ColReducePlan pl = plan_col_reduce(rows, c);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, c,
+    hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, c,
                        pl.rows_per_block);
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
                        (const float*)ws, save_mean, save_rstd, running_mean, running_var, pl.blocks,
-                       rows, c, momentum, eps, (const float*)nullptr);
+                       rows, c, momentum, eps, (const float*)(ws + kColReduceSlabFloats));
 }
 }  // namespace
 
@@ -105,9 +123,9 @@ void batch_statistics(const bf16_raw* x, float* ws, int rows, int c, float* save
 // thread's 8 channels are the same in every grid-stride iteration (the stride is a multiple
 // of c/8), so the per-channel constants are loaded once as 16-byte vectors; the streaming
 // loop is load - fma - max - store with no branches.
-template <bool FROM_VAR>
+template <bool FROM_VAR, typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
-    const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
+    const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean,
     const float* __restrict__ rstd_or_var, int c, float eps, size_t total8) {
     const int c8 = c / 8;
@@ -134,37 +152,74 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     }
     for (; i < total8; i += stride) {
         float v[8], o[8];
-        unpack8(*(const uint4*)(x + i * 8), v);
+        load8(x + i * 8, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = fmaxf(__builtin_fmaf(v[k], sc[k], sh[k]), 0.f);
-        *(uint4*)(y + i * 8) = pack8(o);
+        store8(y + i * 8, o);
     }
 }
+
+namespace {
+template <typename T>
+void bn_fwd_train_launch(const T* x, T* y, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* save_mean,
+                         float* save_rstd, float* ws, int rows, int c, float momentum, float eps,
+                         hipStream_t stream, BnPartials from) {
+    check(rows, c, "bn_relu_fwd_train");
+    batch_statistics(x, ws, rows, c, save_mean, save_rstd, running_mean, running_var, momentum, eps,
+                     from, stream);
+    const size_t total8 = (size_t)rows * (c / 8);
+    hipLaunchKernelGGL((bn_apply_kernel<false, T>), dim3(apply_blocks(total8)), dim3(256), 0, stream,
+                       x, y, gamma, beta, (const float*)save_mean, (const float*)save_rstd, c, eps,
+                       total8);
+}
+
+template <typename T>
+void bn_fwd_eval_launch(const T* x, T* y, const float* gamma, const float* beta,
+                        const float* running_mean, const float* running_var, int rows, int c,
+                        float eps, hipStream_t stream) {
+    check(rows, c, "bn_relu_fwd_eval");
+    const size_t total8 = (size_t)rows * (c / 8);
+    hipLaunchKernelGGL((bn_apply_kernel<true, T>), dim3(apply_blocks(total8)), dim3(256), 0, stream,
+                       x, y, gamma, beta, running_mean, running_var, c, eps, total8);
+}
+}  // namespace
 
 void bn_relu_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float* save_mean,
                        float* save_rstd, float* ws, int rows, int c, float momentum,
                        float eps, hipStream_t stream, BnPartials from) {
-    check(rows, c, "bn_relu_fwd_train");
-    batch_statistics(x, ws, rows, c, save_mean, save_rstd, running_mean, running_var, momentum, eps,
-                     from, stream);
-    const size_t total8 = (size_t)rows * (c / 8);
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(apply_blocks(total8)), dim3(256), 0, stream, x,
-                       y, gamma, beta, (const float*)save_mean, (const float*)save_rstd, c, eps,
-                       total8);
+    bn_fwd_train_launch(x, y, gamma, beta, running_mean, running_var, save_mean, save_rstd, ws,
+                        rows, c, momentum, eps, stream, from);
+}
+void bn_relu_fwd_train(const float* x, float* y, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* save_mean,
+                       float* save_rstd, float* ws, int rows, int c, float momentum,
+                       float eps, hipStream_t stream) {
+    bn_fwd_train_launch(x, y, gamma, beta, running_mean, running_var, save_mean, save_rstd, ws,
+                        rows, c, momentum, eps, stream, BnPartials());
 }
 
 void bn_relu_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, int rows, int c,
                       float eps, hipStream_t stream) {
-    check(rows, c, "bn_relu_fwd_eval");
-    const size_t total8 = (size_t)rows * (c / 8);
-    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(apply_blocks(total8)), dim3(256), 0, stream, x,
-                       y, gamma, beta, running_mean, running_var, c, eps, total8);
+    bn_fwd_eval_launch(x, y, gamma, beta, running_mean, running_var, rows, c, eps, stream);
+}
+void bn_relu_fwd_eval(const float* x, float* y, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, int rows, int c,
+                      float eps, hipStream_t stream) {
+    bn_fwd_eval_launch(x, y, gamma, beta, running_mean, running_var, rows, c, eps, stream);
 }
 
 // The incoming gradient of row r, column group cg: either the stored bf16 tensor, or the sum
 // of a convolution's split slabs - rounded to bf16, stored for the apply pass, and used rounded.
+template <bool SLABS>
+__device__ __forceinline__ void load_dy8(float* __restrict__ dy, SplitSlabs, size_t off,
+                                         float (&g)[8]) {
+    static_assert(!SLABS, "split slabs feed the bf16 path only");
+    load8(dy + off, g);
+}
+
 template <bool SLABS>
 __device__ __forceinline__ void load_dy8(uint16_t* __restrict__ dy, SplitSlabs sl, size_t off,
                                          float (&g)[8]) {
@@ -188,9 +243,9 @@ __device__ __forceinline__ void load_dy8(uint16_t* __restrict__ dy, SplitSlabs s
 // -------------------------------------------------------------------------- backward
 // With xh = (x - mean) * rstd, y = gamma*xh + beta and g = dy * [y > 0]:
 //   dbeta = sum g,  dgamma = sum g*xh,  dx = gamma*rstd * (g - dbeta/n - xh*dgamma/n).
-template <bool SLABS>
+template <bool SLABS, typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const uint16_t* __restrict__ x, uint16_t* __restrict__ dy,
+    const T* __restrict__ x, T* __restrict__ dy,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ ws,
     int rows, int c, int rows_per_block, SplitSlabs sl) {
@@ -205,14 +260,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             mrs[i] = mn[i] * rs[i];
+            // exactly forward's scale / shift, so the mask is the ReLU forward applied
             ysc[i] = gm[i] * rs[i];
-            ysh[i] = bt[i] - gm[i] * mrs[i];
+            ysh[i] = bt[i] - mn[i] * ysc[i];
         }
     }
     column_partials(
         [&](int r, int cg, float (&a)[8], float (&b)[8]) {
             float v[8], g[8];
-            unpack8(*(const uint4*)(x + (size_t)r * c + cg * 8), v);
+            load8(x + (size_t)r * c + cg * 8, v);
             load_dy8<SLABS>(dy, sl, (size_t)r * c + cg * 8, g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -236,8 +292,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restr
         ws, nb, c);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+    const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ dgamma, const float* __restrict__ dbeta, int rows, int c,
@@ -257,7 +314,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             rs[k] = rstd[col];
             const float mrs = mean[col] * rs[k];
             ysc[k] = gamma[col] * rs[k];
-            ysh[k] = beta[col] - gamma[col] * mrs;
+            ysh[k] = beta[col] - mean[col] * ysc[k];      // forward's shift, bit for bit
             k1[k] = gamma[col] * rs[k];
             const float dg = dgamma[col] * inv_n, db = dbeta[col] * inv_n;
             // k1 * (g - db - (x*rs - mrs) * dg) = k1*g - k1*(db - mrs*dg) - (k1*rs*dg) * x
@@ -267,14 +324,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
     for (; i < total8; i += stride) {
         float v[8], g[8], o[8];
-        unpack8(*(const uint4*)(x + i * 8), v);
-        unpack8(*(const uint4*)(dy + i * 8), g);
+        load8(x + i * 8, v);
+        load8(dy + i * 8, g);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float gi = (__builtin_fmaf(v[k], ysc[k], ysh[k]) > 0.f) ? g[k] : 0.f;
             o[k] = k1[k] * gi - k2[k] - k3[k] * v[k];
         }
-        *(uint4*)(dx + i * 8) = pack8(o);
+        store8(dx + i * 8, o);
     }
 }
 
@@ -294,17 +351,36 @@ void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gam
         return;
     const ColReducePlan pl = plan_col_reduce(rows, c);
     if (sl.splits > 0)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(pl.blocks), dim3(256), 0, stream, x, dy,
-                           gamma, beta, save_mean, save_rstd, ws, rows, c, pl.rows_per_block, sl);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, uint16_t>), dim3(pl.blocks), dim3(256), 0,
+                           stream, x, dy, gamma, beta, save_mean, save_rstd, ws, rows, c,
+                           pl.rows_per_block, sl);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(pl.blocks), dim3(256), 0, stream, x, dy,
-                           gamma, beta, save_mean, save_rstd, ws, rows, c, pl.rows_per_block, sl);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, uint16_t>), dim3(pl.blocks), dim3(256), 0,
+                           stream, x, dy, gamma, beta, save_mean, save_rstd, ws, rows, c,
+                           pl.rows_per_block, sl);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
                        (const float*)ws, dgamma, dbeta, pl.blocks, c);
     const size_t total8 = (size_t)rows * (c / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(total8)), dim3(256), 0, stream, x,
-                       (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd, (const float*)dgamma,
-                       (const float*)dbeta, rows, c, total8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<uint16_t>, dim3(apply_blocks(total8)), dim3(256), 0,
+                       stream, x, (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd,
+                       (const float*)dgamma, (const float*)dbeta, rows, c, total8);
+}
+
+// fp32 activations: the same three launches (no split slabs, no one-launch variant)
+void bn_relu_bwd(const float* x, float* dy, float* dx, const float* gamma, const float* beta,
+                 const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                 float* ws, int rows, int c, hipStream_t stream) {
+    check(rows, c, "bn_relu_bwd");
+    const ColReducePlan pl = plan_col_reduce(rows, c);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, float>), dim3(pl.blocks), dim3(256), 0, stream,
+                       x, dy, gamma, beta, save_mean, save_rstd, ws, rows, c, pl.rows_per_block,
+                       SplitSlabs());
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
+                       (const float*)ws, dgamma, dbeta, pl.blocks, c);
+    const size_t total8 = (size_t)rows * (c / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(apply_blocks(total8)), dim3(256), 0, stream,
+                       x, (const float*)dy, dx, gamma, beta, save_mean, save_rstd,
+                       (const float*)dgamma, (const float*)dbeta, rows, c, total8);
 }
 
 

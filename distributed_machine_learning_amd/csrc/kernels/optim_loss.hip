@@ -116,9 +116,9 @@ void cast_bf16_to_f32(const bf16_raw* x, float* out, size_t n, hipStream_t strea
 // out_features <= 16 (10 here): far too narrow for MFMA tiles.  One wave per batch row;
 // each lane owns a contiguous slice of K, keeps `out_features` partial dots in registers
 // and the wave reduces them with xor-shuffles.
-template <int NOUT>
+template <int NOUT, typename T>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(
-    const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ logits, int batch, int k, int nout) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
     for (int k0 = lane * 8; k0 < k; k0 += 64 * 8) {
         float xv[8];
-        unpack8(*(const uint4*)(x + (size_t)row * k + k0), xv);
+        load8(x + (size_t)row * k + k0, xv);
 #pragma unroll
         for (int n = 0; n < NOUT; ++n) {
             if (n < nout) {
@@ -146,14 +146,26 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
     }
 }
 
-void linear_fwd(const bf16_raw* x, const float* w, const float* bias, float* logits, int batch,
-                int in_features, int out_features, hipStream_t stream) {
+namespace {
+template <typename T>
+void linear_fwd_launch(const T* x, const float* w, const float* bias, float* logits, int batch,
+                       int in_features, int out_features, hipStream_t stream) {
     if (out_features < 1 || out_features > 16)
         throw std::invalid_argument("linear_fwd: out_features must be in [1,16]");
     if (in_features % 8 != 0) throw std::invalid_argument("linear_fwd: in_features % 8 != 0");
     if (batch <= 0) return;
-    hipLaunchKernelGGL(linear_fwd_kernel<16>, dim3((batch + 3) / 4), dim3(256), 0, stream, x, w,
-                       bias, logits, batch, in_features, out_features);
+    hipLaunchKernelGGL((linear_fwd_kernel<16, T>), dim3((batch + 3) / 4), dim3(256), 0, stream, x,
+                       w, bias, logits, batch, in_features, out_features);
+}
+}  // namespace
+
+void linear_fwd(const bf16_raw* x, const float* w, const float* bias, float* logits, int batch,
+                int in_features, int out_features, hipStream_t stream) {
+    linear_fwd_launch(x, w, bias, logits, batch, in_features, out_features, stream);
+}
+void linear_fwd(const float* x, const float* w, const float* bias, float* logits, int batch,
+                int in_features, int out_features, hipStream_t stream) {
+    linear_fwd_launch(x, w, bias, logits, batch, in_features, out_features, stream);
 }
 
 // dx[b][k] = sum_n dl[b][n] w[n][k]: one thread per (b, 8 k's).
@@ -298,16 +310,18 @@ constexpr int kFcMaxClasses = 16;
 constexpr int kFcCols = 32;          // feature columns per block of the grads kernel
 constexpr int kFcGroups = 8;         // row groups per block (256 threads = 32 columns x 8 groups)
 
+template <typename T>
 __global__ __launch_bounds__(256) void fc_train_rows_kernel(
-    const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-    const int64_t* __restrict__ target, float* __restrict__ logits, uint16_t* __restrict__ dx,
+    const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const int64_t* __restrict__ target, float* __restrict__ logits, T* __restrict__ dx,
     float* __restrict__ dlogits, float* __restrict__ rowstat, int batch, int k_dim, int n,
     float inv_batch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= batch) return;
     const int kb = lane * 8;                 // k_dim == 512: one 16-byte chunk per lane
-    const uint4 xraw = *(const uint4*)(x + (size_t)row * k_dim + kb);
+    float xv[8];
+    load8(x + (size_t)row * k_dim + kb, xv);
     const int t = (int)target[row];
     float wreg[kFcMaxClasses][8];
 #pragma unroll
@@ -318,8 +332,6 @@ __global__ __launch_bounds__(256) void fc_train_rows_kernel(
             wreg[c][0] = a.x; wreg[c][1] = a.y; wreg[c][2] = a.z; wreg[c][3] = a.w;
             wreg[c][4] = b.x; wreg[c][5] = b.y; wreg[c][6] = b.z; wreg[c][7] = b.w;
         }
-    float xv[8];
-    unpack8(xraw, xv);
     float lg[kFcMaxClasses];
     float mx = -3.0e38f;
     int arg = 0;
@@ -358,21 +370,28 @@ __global__ __launch_bounds__(256) void fc_train_rows_kernel(
         rowstat[(size_t)row * 2] = (mx + __logf(se) - lt) * inv_batch;
         rowstat[(size_t)row * 2 + 1] = (arg == t) ? 1.f : 0.f;
     }
-    if (dx) *(uint4*)(dx + (size_t)row * k_dim + kb) = pack8(o);
+    if (dx) store8(dx + (size_t)row * k_dim + kb, o);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void fc_train_grads_kernel(
-    const uint16_t* __restrict__ x, const float* __restrict__ dlogits,
+    const T* __restrict__ x, const float* __restrict__ dlogits,
     const float* __restrict__ rowstat, float* __restrict__ dw, float* __restrict__ db,
     float* __restrict__ loss, int32_t* __restrict__ correct, int batch, int k_dim, int n) {
     // The kernel is a latency chain, not a bandwidth problem: 256 rows of its 32 columns and
     // of dlogits are staged in LDS with every global load issued up front (one round trip per
     // 256 rows), and the sums run out of LDS.
     constexpr int kTile = 256;
-    __shared__ __attribute__((aligned(16))) uint16_t sx[kTile][kFcCols];
+    // the staged x tile keeps the storage type; the fold scratch `red` reuses its bytes once the
+    // last tile has been consumed
+    __shared__ __attribute__((aligned(16))) char sx_bytes[kTile * kFcCols * 4];
     __shared__ __attribute__((aligned(16))) float sd[kTile][kFcMaxClasses];
     __shared__ float2 sr[kTile];
-    __shared__ float red[kFcGroups][kFcMaxClasses][kFcCols + 1];
+    static_assert(sizeof(float) * kFcGroups * kFcMaxClasses * (kFcCols + 1) <= sizeof(sx_bytes),
+                  "fold scratch must fit the x tile");
+    T (*sx)[kFcCols] = reinterpret_cast<T (*)[kFcCols]>(sx_bytes);
+    float (*red)[kFcMaxClasses][kFcCols + 1] =
+        reinterpret_cast<float (*)[kFcMaxClasses][kFcCols + 1]>(sx_bytes);
     const int col = threadIdx.x % kFcCols, grp = threadIdx.x / kFcCols;
     const int f0 = blockIdx.x * kFcCols;
     // batch sums of dlogits (db, block 0) and of the loss terms / hits (block 1) come out of
@@ -383,14 +402,13 @@ __global__ __launch_bounds__(256) void fc_train_grads_kernel(
 #pragma unroll
     for (int c = 0; c < kFcMaxClasses; ++c) acc[c] = 0.f;
     for (int base = 0; base < batch; base += kTile) {
-        uint4 xr[4];
+        Raw8<T> xr[4];
         float4 dr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = threadIdx.x + 256 * i;
             const int rx = base + (id >> 2), rd = base + (id >> 2);
-            xr[i] = rx < batch ? *(const uint4*)(x + (size_t)rx * k_dim + f0 + (id & 3) * 8)
-                               : make_uint4(0, 0, 0, 0);
+            xr[i] = rx < batch ? load_raw8(x + (size_t)rx * k_dim + f0 + (id & 3) * 8) : Raw8<T>();
             dr[i] = rd < batch ? *(const float4*)(dlogits + (size_t)rd * kFcMaxClasses + (id & 3) * 4)
                                : float4{0.f, 0.f, 0.f, 0.f};
         }
@@ -401,13 +419,13 @@ __global__ __launch_bounds__(256) void fc_train_grads_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = threadIdx.x + 256 * i;
-            *(uint4*)(&sx[id >> 2][(id & 3) * 8]) = xr[i];
+            store_raw8(&sx[id >> 2][(id & 3) * 8], xr[i]);
             *(float4*)(&sd[id >> 2][(id & 3) * 4]) = dr[i];
         }
         __syncthreads();
 #pragma unroll 4
         for (int r = grp; r < kTile; r += kFcGroups) {
-            const float xv = bf16_bits_to_float(sx[r][col]);
+            const float xv = elem_to_float(sx[r][col]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 d = *(const float4*)(&sd[r][4 * q]);
@@ -423,6 +441,7 @@ __global__ __launch_bounds__(256) void fc_train_grads_kernel(
             for (int r = g16; r < kTile; r += 16) tail += c16 ? sr[r].y : sr[r].x;
         }
     }
+    __syncthreads();        // every thread is done with the staged tiles: `red` may take over
 #pragma unroll
     for (int c = 0; c < kFcMaxClasses; ++c) red[grp][c][col] = acc[c];
     __syncthreads();
@@ -469,26 +488,50 @@ void fc_check(int batch, int in_features, int out_features) {
 }
 }  // namespace
 
-void fc_train_rows(const bf16_raw* x, const float* w, const float* bias, const int64_t* target,
-                   float* logits, bf16_raw* dx, float* ws, int batch, int in_features,
-                   int out_features, hipStream_t stream) {
+namespace {
+template <typename T>
+void fc_rows_launch(const T* x, const float* w, const float* bias, const int64_t* target,
+                    float* logits, T* dx, float* ws, int batch, int in_features, int out_features,
+                    hipStream_t stream) {
     fc_check(batch, in_features, out_features);
     if (batch <= 0) return;
     float* dlogits = ws;
     float* rowstat = ws + (size_t)batch * kFcMaxClasses;
-    hipLaunchKernelGGL(fc_train_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, x, w, bias,
-                       target, logits, dx, dlogits, rowstat, batch, in_features, out_features,
+    hipLaunchKernelGGL(fc_train_rows_kernel<T>, dim3((batch + 3) / 4), dim3(256), 0, stream, x, w,
+                       bias, target, logits, dx, dlogits, rowstat, batch, in_features, out_features,
                        1.0f / (float)batch);
 }
 
-void fc_train_grads(const bf16_raw* x, const float* ws, float* loss, int32_t* correct, float* dw,
-                    float* db, int batch, int in_features, int out_features, hipStream_t stream) {
+template <typename T>
+void fc_grads_launch(const T* x, const float* ws, float* loss, int32_t* correct, float* dw,
+                     float* db, int batch, int in_features, int out_features, hipStream_t stream) {
     fc_check(batch, in_features, out_features);
     if (batch <= 0) return;
     const float* dlogits = ws;
     const float* rowstat = ws + (size_t)batch * kFcMaxClasses;
-    hipLaunchKernelGGL(fc_train_grads_kernel, dim3(in_features / kFcCols), dim3(256), 0, stream, x,
-                       dlogits, rowstat, dw, db, loss, correct, batch, in_features, out_features);
+    hipLaunchKernelGGL(fc_train_grads_kernel<T>, dim3(in_features / kFcCols), dim3(256), 0, stream,
+                       x, dlogits, rowstat, dw, db, loss, correct, batch, in_features, out_features);
+}
+}  // namespace
+
+void fc_train_rows(const bf16_raw* x, const float* w, const float* bias, const int64_t* target,
+                   float* logits, bf16_raw* dx, float* ws, int batch, int in_features,
+                   int out_features, hipStream_t stream) {
+    fc_rows_launch(x, w, bias, target, logits, dx, ws, batch, in_features, out_features, stream);
+}
+void fc_train_rows(const float* x, const float* w, const float* bias, const int64_t* target,
+                   float* logits, float* dx, float* ws, int batch, int in_features,
+                   int out_features, hipStream_t stream) {
+    fc_rows_launch(x, w, bias, target, logits, dx, ws, batch, in_features, out_features, stream);
+}
+
+void fc_train_grads(const bf16_raw* x, const float* ws, float* loss, int32_t* correct, float* dw,
+                    float* db, int batch, int in_features, int out_features, hipStream_t stream) {
+    fc_grads_launch(x, ws, loss, correct, dw, db, batch, in_features, out_features, stream);
+}
+void fc_train_grads(const float* x, const float* ws, float* loss, int32_t* correct, float* dw,
+                    float* db, int batch, int in_features, int out_features, hipStream_t stream) {
+    fc_grads_launch(x, ws, loss, correct, dw, db, batch, in_features, out_features, stream);
 }
 
 void fc_train(const bf16_raw* x, const float* w, const float* bias, const int64_t* target,

@@ -21,8 +21,9 @@ __device__ __forceinline__ void max8(float (&m)[8], const float (&v)[8]) {
 }
 
 // ---------------------------------------------------------------------- maxpool fwd
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const uint16_t* __restrict__ x,
-                                                          uint16_t* __restrict__ y, int hw, int c,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x,
+                                                          T* __restrict__ y, int hw, int c,
                                                           size_t total) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -32,30 +33,41 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const uint16_t* __rest
     const int ow = (int)(r % ohw); r /= ohw;
     const int oh = (int)(r % ohw);
     const size_t b = r / ohw;
-    const uint16_t* src = x + (((b * hw + 2 * oh) * hw + 2 * ow) * c) + cc * 8;
+    const T* src = x + (((b * hw + 2 * oh) * hw + 2 * ow) * c) + cc * 8;
     float m[8], v[8];
-    unpack8(*(const uint4*)src, m);
-    unpack8(*(const uint4*)(src + c), v); max8(m, v);
-    unpack8(*(const uint4*)(src + (size_t)hw * c), v); max8(m, v);
-    unpack8(*(const uint4*)(src + (size_t)hw * c + c), v); max8(m, v);
-    *(uint4*)(y + idx * 8) = pack8(m);
+    load8(src, m);
+    load8(src + c, v); max8(m, v);
+    load8(src + (size_t)hw * c, v); max8(m, v);
+    load8(src + (size_t)hw * c + c, v); max8(m, v);
+    store8(y + idx * 8, m);
 }
 
-void maxpool2x2_fwd(const bf16_raw* x, bf16_raw* y, int batch, int hw, int c, hipStream_t stream) {
+namespace {
+template <typename T>
+void maxpool_fwd_launch(const T* x, T* y, int batch, int hw, int c, hipStream_t stream) {
     if (hw < 2 || (hw & 1) || c % 8) throw std::invalid_argument("maxpool2x2_fwd: bad shape");
     const size_t total = (size_t)batch * (hw / 2) * (hw / 2) * (c / 8);
     if (total == 0) return;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        stream, x, y, hw, c, total);
+}
+}  // namespace
+
+void maxpool2x2_fwd(const bf16_raw* x, bf16_raw* y, int batch, int hw, int c, hipStream_t stream) {
+    maxpool_fwd_launch(x, y, batch, hw, c, stream);
+}
+void maxpool2x2_fwd(const float* x, float* y, int batch, int hw, int c, hipStream_t stream) {
+    maxpool_fwd_launch(x, y, batch, hw, c, stream);
 }
 
 // ---------------------------------------------------------------------- maxpool bwd
 // One thread per pooled position x 8 channels: re-derives the arg-max from the saved
 // input (first maximum in row-major window order, like the index the forward of a
 // framework pool records), writes all four input positions (zeros off the route).
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint16_t* __restrict__ x,
-                                                          const uint16_t* __restrict__ dy,
-                                                          uint16_t* __restrict__ dx, int hw, int c,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x,
+                                                          const T* __restrict__ dy,
+                                                          T* __restrict__ dx, int hw, int c,
                                                           size_t total, int relu_mask) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -69,8 +81,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint16_t* __rest
     const size_t off[4] = {0, (size_t)c, (size_t)hw * c, (size_t)hw * c + c};
     float v[4][8], g[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) unpack8(*(const uint4*)(x + base + off[q]), v[q]);
-    unpack8(*(const uint4*)(dy + idx * 8), g);
+    for (int q = 0; q < 4; ++q) load8(x + base + off[q], v[q]);
+    load8(dy + idx * 8, g);
     float o[4][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -84,29 +96,42 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint16_t* __rest
         for (int q = 0; q < 4; ++q) o[q][i] = (q == arg) ? gi : 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *(uint4*)(dx + base + off[q]) = pack8(o[q]);
+    for (int q = 0; q < 4; ++q) store8(dx + base + off[q], o[q]);
 }
 
-void maxpool2x2_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, int batch, int hw, int c,
-                    bool relu_mask, hipStream_t stream) {
+namespace {
+template <typename T>
+void maxpool_bwd_launch(const T* x, const T* dy, T* dx, int batch, int hw, int c, bool relu_mask,
+                        hipStream_t stream) {
     if (hw < 2 || (hw & 1) || c % 8) throw std::invalid_argument("maxpool2x2_bwd: bad shape");
     const size_t total = (size_t)batch * (hw / 2) * (hw / 2) * (c / 8);
     if (total == 0) return;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        stream, x, dy, dx, hw, c, total, relu_mask ? 1 : 0);
+}
+}  // namespace
+
+void maxpool2x2_bwd(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, int batch, int hw, int c,
+                    bool relu_mask, hipStream_t stream) {
+    maxpool_bwd_launch(x, dy, dx, batch, hw, c, relu_mask, stream);
+}
+void maxpool2x2_bwd(const float* x, const float* dy, float* dx, int batch, int hw, int c,
+                    bool relu_mask, hipStream_t stream) {
+    maxpool_bwd_launch(x, dy, dx, batch, hw, c, relu_mask, stream);
 }
 
 // ----------------------------------------------------------------------- column sum
 // out[c] += sum over rows (bias gradients): partial rows per block, then a small fold
 // kernel (dml_column_reduce.h); no atomics on `out`.
-__global__ __launch_bounds__(256) void column_sum_kernel(const uint16_t* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void column_sum_kernel(const T* __restrict__ x,
                                                          float* __restrict__ ws, int rows, int c,
                                                          int rows_per_block) {
     __shared__ float red[4096];
     column_partials(
         [&](int r, int cg, float (&a)[8], float (&b)[8]) {
             float v[8];
-            unpack8(*(const uint4*)(x + (size_t)r * c + cg * 8), v);
+            load8(x + (size_t)r * c + cg * 8, v);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] += v[i];
         },
@@ -121,16 +146,26 @@ __global__ __launch_bounds__(256) void column_sum_finish_kernel(const float* __r
 
 size_t column_sum_workspace_elems() { return kColReduceWsFloats; }
 
-void column_sum(const bf16_raw* x, float* out, int rows, int cols, float* ws, hipStream_t stream) {
+namespace {
+template <typename T>
+void column_sum_launch(const T* x, float* out, int rows, int cols, float* ws, hipStream_t stream) {
     if (cols % 8 || cols < 8 || cols > 2048 || (256 % (cols / 8)) != 0)
         throw std::invalid_argument("column_sum: cols must be 8*2^k, <= 2048");
     if (!ws) throw std::invalid_argument("column_sum: workspace missing");
     if (rows <= 0) return;
     const ColReducePlan pl = plan_col_reduce(rows, cols);
-    hipLaunchKernelGGL(column_sum_kernel, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, cols,
-                       pl.rows_per_block);
+    hipLaunchKernelGGL(column_sum_kernel<T>, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows,
+                       cols, pl.rows_per_block);
     hipLaunchKernelGGL(column_sum_finish_kernel, dim3(fold_blocks(cols)), dim3(256), 0, stream,
                        (const float*)ws, out, pl.blocks, cols);
+}
+}  // namespace
+
+void column_sum(const bf16_raw* x, float* out, int rows, int cols, float* ws, hipStream_t stream) {
+    column_sum_launch(x, out, rows, cols, ws, stream);
+}
+void column_sum(const float* x, float* out, int rows, int cols, float* ws, hipStream_t stream) {
+    column_sum_launch(x, out, rows, cols, ws, stream);
 }
 
 // ------------------------------------------------------------- augmentation + normalise
@@ -138,9 +173,20 @@ void column_sum(const bf16_raw* x, float* out, int rows, int cols, float* ws, hi
 // applied before normalisation, 8-byte bf16 NHWC4 store.
 struct Norm3 { float mean[3]; float inv_std[3]; };
 
+__device__ __forceinline__ void store_pixel4(uint16_t* p, float a, float b, float c) {
+    uint2 o;
+    o.x = pack2(a, b);
+    o.y = pack2(c, 0.f);
+    *(uint2*)p = o;
+}
+__device__ __forceinline__ void store_pixel4(float* p, float a, float b, float c) {
+    *(float4*)p = float4{a, b, c, 0.f};
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict__ img,
                                                       const int32_t* __restrict__ aug,
-                                                      uint16_t* __restrict__ out, size_t total,
+                                                      T* __restrict__ out, size_t total,
                                                       Norm3 nm) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -157,40 +203,53 @@ __global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict_
         const uint8_t* p = img + ((b * 32 + sy) * 32 + sx) * 3;
         v[0] = p[0] * (1.f / 255.f); v[1] = p[1] * (1.f / 255.f); v[2] = p[2] * (1.f / 255.f);
     }
-    uint2 o;
-    o.x = pack2((v[0] - nm.mean[0]) * nm.inv_std[0], (v[1] - nm.mean[1]) * nm.inv_std[1]);
-    o.y = pack2((v[2] - nm.mean[2]) * nm.inv_std[2], 0.f);
-    *(uint2*)(out + idx * 4) = o;
+    store_pixel4(out + idx * 4, (v[0] - nm.mean[0]) * nm.inv_std[0],
+                 (v[1] - nm.mean[1]) * nm.inv_std[1], (v[2] - nm.mean[2]) * nm.inv_std[2]);
 }
 
-void augment_normalize(const uint8_t* images, const int32_t* aug, bf16_raw* out, int batch,
-                       const float mean[3], const float stdv[3], hipStream_t stream) {
+namespace {
+template <typename T>
+void augment_launch(const uint8_t* images, const int32_t* aug, T* out, int batch,
+                    const float mean[3], const float stdv[3], hipStream_t stream) {
     if (batch <= 0) return;
     Norm3 nm;
     for (int i = 0; i < 3; ++i) { nm.mean[i] = mean[i]; nm.inv_std[i] = 1.f / stdv[i]; }
     const size_t total = (size_t)batch * 1024;
-    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       images, aug, out, total, nm);
+    hipLaunchKernelGGL(augment_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       stream, images, aug, out, total, nm);
+}
+}  // namespace
+
+void augment_normalize(const uint8_t* images, const int32_t* aug, bf16_raw* out, int batch,
+                       const float mean[3], const float stdv[3], hipStream_t stream) {
+    augment_launch(images, aug, out, batch, mean, stdv, stream);
+}
+void augment_normalize(const uint8_t* images, const int32_t* aug, float* out, int batch,
+                       const float mean[3], const float stdv[3], hipStream_t stream) {
+    augment_launch(images, aug, out, batch, mean, stdv, stream);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x,
-                                                            uint16_t* __restrict__ out,
-                                                            size_t total) {
+                                                            T* __restrict__ out, size_t total) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const size_t b = idx >> 10, pix = idx & 1023;
     const float* p = x + b * 3072 + pix;
-    uint2 o;
-    o.x = pack2(p[0], p[1024]);
-    o.y = pack2(p[2048], 0.f);
-    *(uint2*)(out + idx * 4) = o;
+    store_pixel4(out + idx * 4, p[0], p[1024], p[2048]);
 }
 
 void nchw_to_nhwc4(const float* x, bf16_raw* out, int batch, hipStream_t stream) {
     if (batch <= 0) return;
     const size_t total = (size_t)batch * 1024;
-    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       stream, x, out, total);
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel<uint16_t>, dim3((unsigned)((total + 255) / 256)),
+                       dim3(256), 0, stream, x, out, total);
+}
+void nchw_to_nhwc4(const float* x, float* out, int batch, hipStream_t stream) {
+    if (batch <= 0) return;
+    const size_t total = (size_t)batch * 1024;
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel<float>, dim3((unsigned)((total + 255) / 256)),
+                       dim3(256), 0, stream, x, out, total);
 }
 
 // Generic layout converters (tests, eager API boundary; not on the training hot path).

@@ -70,13 +70,13 @@ def _augment_reference(images_u8: torch.Tensor, aug: Optional[torch.Tensor]) -> 
 class BatchTransform:
     """Callable handed to ``BatchLoader``.
 
-    ``layout="nchw_fp32"`` feeds the stock-torch model; ``layout="nhwc4_bf16"``
-    produces the channel-padded bf16 NHWC batch the native conv1 kernel reads and
-    runs the fused HIP kernel when the batch lives on a GPU.
+    ``layout="nchw_fp32"`` feeds the stock-torch model; ``layout="nhwc4_bf16"`` /
+    ``"nhwc4_fp32"`` produce the channel-padded NHWC batch the native first-layer kernels
+    read (bf16 or fp32 engine) and run the fused HIP kernel when the batch lives on a GPU.
     """
 
     def __init__(self, train: bool, layout: str = "nchw_fp32", seed: int = 0):
-        if layout not in ("nchw_fp32", "nhwc4_bf16"):
+        if layout not in ("nchw_fp32", "nhwc4_bf16", "nhwc4_fp32"):
             raise ValueError(layout)
         self.train = train
         self.layout = layout
@@ -91,10 +91,11 @@ class BatchTransform:
             aug = draw_augmentation(index.to(images_u8.device), self.seed, self.epoch)
         if self.layout == "nchw_fp32":
             return _augment_reference(images_u8, aug)
+        dtype = torch.bfloat16 if self.layout == "nhwc4_bf16" else torch.float32
         if images_u8.is_cuda:
             from ..ops import native
-            return native.augment_normalize(images_u8, aug)
+            return native.augment_normalize(images_u8, aug, dtype)
         x = _augment_reference(images_u8, aug).permute(0, 2, 3, 1)
-        out = torch.zeros(x.shape[0], HW, HW, 4, dtype=torch.bfloat16, device=x.device)
-        out[..., :3] = x.to(torch.bfloat16)
+        out = torch.zeros(x.shape[0], HW, HW, 4, dtype=dtype, device=x.device)
+        out[..., :3] = x.to(dtype)
         return out

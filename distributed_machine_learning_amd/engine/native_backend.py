@@ -24,29 +24,37 @@ from ..parallel.flat import cap_tail_bucket
 
 
 class NativeBackend:
+    """``cfg.dtype`` selects the engine: ``bf16`` (default) = bf16 activations and MFMA operands
+    with fp32 master weights, accumulators and statistics (``VggEngine``); ``fp32`` = the
+    reference's precision, every tensor fp32, fp32-input MFMA (``VggEngineF32``)."""
+
     name = "native"
-    loader_layout = "nhwc4_bf16"
 
     def __init__(self, cfg: TrainConfig, device: torch.device, comm: Optional[Communicator],
                  init_state: Optional[Dict[str, torch.Tensor]] = None):
-        if cfg.dtype not in ("bf16", "auto"):
-            raise NotImplementedError(
-                "the native engine computes in bf16 with fp32 master weights, accumulators and "
-                "statistics; use --backend torch for an all-fp32 run")
+        if cfg.dtype not in ("bf16", "fp32", "auto"):
+            raise ValueError(f"native backend: dtype must be bf16 or fp32, got {cfg.dtype!r}")
+        self.fp32 = cfg.dtype == "fp32"
+        self.act_dtype = torch.float32 if self.fp32 else torch.bfloat16
+        self.loader_layout = "nhwc4_fp32" if self.fp32 else "nhwc4_bf16"
+        if self.fp32 and cfg.use_graph:
+            raise ValueError("--graph replays the bf16 engine's step; the fp32 engine has no "
+                             "graph mode")
         self.cfg = cfg
         self.device = device
         self.comm = comm
         self.world = comm.world_size if comm is not None else 1
         C = native.lib()
         widths = [-1 if w == "M" else int(w) for w in VGG_WIDTHS[cfg.arch]]
-        self.engine = C.VggEngine(widths, cfg.batch_size, cfg.batch_norm, cfg.num_classes)
+        engine_cls = C.VggEngineF32 if self.fp32 else C.VggEngine
+        self.engine = engine_cls(widths, cfg.batch_size, cfg.batch_norm, cfg.num_classes)
         e = self.engine
         f32 = dict(dtype=torch.float32, device=device)
         self.params = torch.zeros(e.param_elems, **f32)
         self.grads = torch.zeros(e.param_elems, **f32)
         self.momentum = torch.zeros(e.param_elems, **f32)
         self.bn_buffers = torch.zeros(max(e.bn_elems, 1), **f32)
-        self.arena = torch.zeros(e.arena_elems, dtype=torch.bfloat16, device=device)
+        self.arena = torch.zeros(e.arena_elems, dtype=self.act_dtype, device=device)
         self.workspace = torch.zeros(e.workspace_elems, **f32)
         e.bind(self.params.data_ptr(), self.grads.data_ptr(), self.momentum.data_ptr(),
                self.bn_buffers.data_ptr() if cfg.batch_norm else 0, self.arena.data_ptr(),
@@ -73,12 +81,16 @@ class NativeBackend:
         # layers per hand-off (each costs ~15 us of host time and a cross-queue hop): one layer
         # per hand-off measured best with and without a reducer (0.712 vs 0.732 ms with one)
         group = int(cfg.wgrad_group) or 1
-        e.set_wgrad_overlap(bool(cfg.wgrad_overlap) and not cfg.serialize_streams, group,
-                            self._stream())
-        # the optimizer update can run inside backward when the gradients backward leaves
-        # behind are final: no sync, or the bucket reducer (the two manual modes synchronise
-        # after backward has ended)
-        self._fuse_opt = bool(cfg.fused_optimizer) and e.wgrad_overlap and self.manual is None
+        if self.fp32:
+            # the fp32 step is bound by the convolutions' arithmetic: one stream, no fusion
+            self._fuse_opt = False
+        else:
+            e.set_wgrad_overlap(bool(cfg.wgrad_overlap) and not cfg.serialize_streams, group,
+                                self._stream())
+            # the optimizer update can run inside backward when the gradients backward leaves
+            # behind are final: no sync, or the bucket reducer (the two manual modes
+            # synchronise after backward has ended)
+            self._fuse_opt = bool(cfg.fused_optimizer) and e.wgrad_overlap and self.manual is None
         self._graph_ready = False
         self._x_static = None
         self._t_static = None
@@ -229,8 +241,8 @@ class NativeBackend:
         self._training = on
 
     def _check_batch(self, data: torch.Tensor, target: torch.Tensor) -> int:
-        if data.dtype != torch.bfloat16 or data.dim() != 4 or tuple(data.shape[1:]) != (32, 32, 4):
-            raise ValueError(f"native backend expects bf16 [B,32,32,4] input, got "
+        if data.dtype != self.act_dtype or data.dim() != 4 or tuple(data.shape[1:]) != (32, 32, 4):
+            raise ValueError(f"native backend expects {self.act_dtype} [B,32,32,4] input, got "
                              f"{data.dtype} {tuple(data.shape)}")
         n = int(data.shape[0])
         if n > self.cfg.batch_size or target.shape[0] != n or target.dtype != torch.int64:
@@ -243,8 +255,9 @@ class NativeBackend:
         cfg, e = self.cfg, self.engine
         n = self._check_batch(data, target)
         s = self._stream()
-        e.set_fused_optimizer(self._fuse_opt, cfg.lr, cfg.momentum, cfg.weight_decay,
-                              self._grad_scale)
+        if not self.fp32:
+            e.set_fused_optimizer(self._fuse_opt, cfg.lr, cfg.momentum, cfg.weight_decay,
+                                  self._grad_scale)
         if cfg.use_graph and self.world == 1:
             return self._train_step_graph(data, target, n, s)
         e.train_step(data.data_ptr(), target.data_ptr(), n, cfg.lr, cfg.momentum, cfg.weight_decay,

@@ -44,10 +44,9 @@ def resolve_device(cfg: TrainConfig, local_rank: int = 0) -> torch.device:
 def resolve_backend(cfg: TrainConfig, device: torch.device) -> str:
     if cfg.backend != "auto":
         return cfg.backend
-    # the native engine is bf16-compute / fp32-master; an all-fp32 run uses the stock modules
-    if device.type == "cuda" and cfg.dtype != "fp32":
-        return "native"
-    return "torch"
+    # a GPU always runs the native kernels (bf16 or fp32 engine, by --dtype); stock torch is the
+    # CPU configuration and, on a GPU, an explicit --backend torch (the golden model)
+    return "native" if device.type == "cuda" else "torch"
 
 
 def make_backend(cfg: TrainConfig, device: torch.device, comm: Optional[Communicator]):

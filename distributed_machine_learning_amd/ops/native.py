@@ -447,15 +447,20 @@ def sgd_momentum_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, lr: float, 
 
 
 # --------------------------------------------------------------- data and helpers
-def augment_normalize(images_u8: torch.Tensor, aug: Optional[torch.Tensor]) -> torch.Tensor:
-    """uint8 ``[B,32,32,3]`` -> bf16 ``[B,32,32,4]`` (crop/flip per ``aug`` row, normalised)."""
+def augment_normalize(images_u8: torch.Tensor, aug: Optional[torch.Tensor],
+                      dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """uint8 ``[B,32,32,3]`` -> bf16 or fp32 ``[B,32,32,4]`` (crop/flip per ``aug`` row,
+    normalised)."""
     _req(images_u8, torch.uint8, "images", 4)
     b = images_u8.shape[0]
     if aug is not None:
         _req(aug, torch.int32, "aug", 2)
-    out = torch.empty(b, 32, 32, 4, dtype=torch.bfloat16, device=images_u8.device)
-    lib().augment_normalize(images_u8.data_ptr(), _ptr(aug), out.data_ptr(), b, list(CIFAR_MEAN),
-                            list(CIFAR_STD), _stream())
+    out = torch.empty(b, 32, 32, 4, dtype=dtype, device=images_u8.device)
+    fn = lib().augment_normalize if dtype == torch.bfloat16 else lib().augment_normalize_f32
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("augment_normalize: bf16 or fp32 output")
+    fn(images_u8.data_ptr(), _ptr(aug), out.data_ptr(), b, list(CIFAR_MEAN), list(CIFAR_STD),
+       _stream())
     return out
 
 
@@ -495,3 +500,193 @@ def fill_uniform_(t: torch.Tensor, seed: int, scale: float = 1.0) -> torch.Tenso
     _req(t, torch.bfloat16, "t")
     lib().fill_uniform_bf16(t.data_ptr(), t.numel(), seed, scale, _stream())
     return t
+
+
+# ------------------------------------------------------------------ fp32 activations
+# The reference's precision: NHWC fp32 tensors, conv weights ``[Cout,3,3,Cin]`` fp32.
+F32 = torch.float32
+
+
+def conv3x3_fwd_f32(x, wf, bias=None, relu=True, tile=0):
+    _req(x, F32, "x", 4)
+    _req(wf, F32, "wf", 4)
+    b, h, w, cin = x.shape
+    cout = wf.shape[0]
+    if h != w or tuple(wf.shape[1:]) != (3, 3, cin):
+        raise ValueError(f"conv3x3_fwd_f32: x {tuple(x.shape)} vs wf {tuple(wf.shape)}")
+    if bias is not None:
+        _req(bias, F32, "bias", 1)
+    y = torch.empty(b, h, w, cout, dtype=F32, device=x.device)
+    epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    lib().conv3x3_igemm_f32(x.data_ptr(), wf.data_ptr(), y.data_ptr(), _ptr(bias), 0, b, h, cin, cout,
+                            epi, _stream(), tile)
+    return y
+
+
+def repack_dgrad_f32(wf):
+    _req(wf, F32, "wf", 4)
+    cout, _, _, cin = wf.shape
+    wd = torch.empty(cin, 3, 3, cout, dtype=F32, device=wf.device)
+    lib().repack_dgrad_weights_f32(wf.data_ptr(), wd.data_ptr(), cout, cin, _stream())
+    return wd
+
+
+def conv3x3_dgrad_f32(dy, wd, relu_mask=None, tile=0):
+    _req(dy, F32, "dy", 4)
+    _req(wd, F32, "wd", 4)
+    b, h, w, cout = dy.shape
+    cin = wd.shape[0]
+    if h != w or tuple(wd.shape[1:]) != (3, 3, cout):
+        raise ValueError("conv3x3_dgrad_f32: shape mismatch")
+    dx = torch.empty(b, h, w, cin, dtype=F32, device=dy.device)
+    if relu_mask is not None:
+        _req(relu_mask, F32, "relu_mask", 4)
+        if relu_mask.shape != dx.shape:
+            raise ValueError("conv3x3_dgrad_f32: mask shape")
+    lib().conv3x3_igemm_f32(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0, _ptr(relu_mask), b, h, cout,
+                            cin, EPI_MASK if relu_mask is not None else EPI_NONE, _stream(), tile)
+    return dx
+
+
+def conv3x3_wgrad_f32(x, dy, splits=0):
+    _req(x, F32, "x", 4)
+    _req(dy, F32, "dy", 4)
+    b, h, w, cin = x.shape
+    cout = dy.shape[3]
+    if tuple(dy.shape[:3]) != (b, h, w) or h != w:
+        raise ValueError("conv3x3_wgrad_f32: shape mismatch")
+    dw = torch.empty(cout, 3, 3, cin, dtype=F32, device=x.device)
+    n = lib().conv3x3_wgrad_f32_splits(b, h, cin, cout, splits)
+    slab = torch.empty(n, dw.numel(), dtype=F32, device=x.device)
+    lib().conv3x3_wgrad_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), b, h, cin, cout,
+                            slab.data_ptr(), _stream(), splits)
+    if n > 1:       # the engine sums the splits with sum_slabs_batch; here a tensor op does
+        dw = slab.sum(dim=0).view_as(dw)
+    return dw
+
+
+def conv1_fwd_f32(x4, w, bias, relu=True):
+    _req(x4, F32, "x4", 4)
+    _req(w, F32, "w", 4)
+    _req(bias, F32, "bias", 1)
+    b = x4.shape[0]
+    if tuple(x4.shape[1:]) != (32, 32, 4) or tuple(w.shape) != (64, 3, 3, 3) or bias.numel() != 64:
+        raise ValueError("conv1_fwd_f32: expects x [B,32,32,4], w [64,3,3,3], bias [64]")
+    y = torch.empty(b, 32, 32, 64, dtype=F32, device=x4.device)
+    lib().conv1_fprop_f32(x4.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), b, relu, _stream())
+    return y
+
+
+def conv1_wgrad_f32(x4, dy):
+    _req(x4, F32, "x4", 4)
+    _req(dy, F32, "dy", 4)
+    b = x4.shape[0]
+    if tuple(x4.shape[1:]) != (32, 32, 4) or tuple(dy.shape) != (b, 32, 32, 64):
+        raise ValueError("conv1_wgrad_f32: shape mismatch")
+    dw = torch.empty(64, 3, 3, 3, dtype=F32, device=x4.device)
+    db = torch.empty(64, dtype=F32, device=x4.device)
+    ws = torch.empty(lib().conv1_wgrad_f32_workspace_elems(b), dtype=F32, device=x4.device)
+    lib().conv1_wgrad_f32(x4.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), b,
+                          ws.data_ptr(), _stream())
+    return dw, db
+
+
+def maxpool2x2_fwd_f32(x):
+    _req(x, F32, "x", 4)
+    b, h, w, c = x.shape
+    y = torch.empty(b, h // 2, w // 2, c, dtype=F32, device=x.device)
+    lib().maxpool2x2_fwd_f32(x.data_ptr(), y.data_ptr(), b, h, c, _stream())
+    return y
+
+
+def maxpool2x2_bwd_f32(x, dy, relu_mask=False):
+    _req(x, F32, "x", 4)
+    _req(dy, F32, "dy", 4)
+    b, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    lib().maxpool2x2_bwd_f32(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), b, h, c, relu_mask, _stream())
+    return dx
+
+
+def bn_relu_fwd_train_f32(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1,
+                          eps=1e-5):
+    _req(x, F32, "x")
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    mean = torch.empty(c, dtype=F32, device=x.device)
+    rstd = torch.empty(c, dtype=F32, device=x.device)
+    lib().bn_relu_fwd_train_f32(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
+                                rstd.data_ptr(), _reduce_ws(x.device).data_ptr(), x.numel() // c, c,
+                                momentum, eps, _stream())
+    return y, mean, rstd
+
+
+def bn_relu_fwd_eval_f32(x, gamma, beta, running_mean, running_var, eps=1e-5):
+    _req(x, F32, "x")
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    lib().bn_relu_fwd_eval_f32(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                               running_mean.data_ptr(), running_var.data_ptr(), x.numel() // c, c,
+                               eps, _stream())
+    return y
+
+
+def bn_relu_bwd_f32(x, dy, gamma, beta, save_mean, save_rstd):
+    _req(x, F32, "x")
+    _req(dy, F32, "dy")
+    c = x.shape[-1]
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=F32, device=x.device)
+    dbeta = torch.empty(c, dtype=F32, device=x.device)
+    lib().bn_relu_bwd_f32(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(),
+                          beta.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
+                          dgamma.data_ptr(), dbeta.data_ptr(), _reduce_ws(x.device).data_ptr(),
+                          x.numel() // c, c, _stream())
+    return dx, dgamma, dbeta
+
+
+def column_sum_f32(x):
+    _req(x, F32, "x")
+    c = x.shape[-1]
+    out = torch.empty(c, dtype=F32, device=x.device)
+    lib().column_sum_f32(x.data_ptr(), out.data_ptr(), x.numel() // c, c,
+                         _reduce_ws(x.device).data_ptr(), _stream())
+    return out
+
+
+def fc_train_f32(x, w, bias, target):
+    """Fused classifier step on fp32 features: ``(logits, loss[1], correct[1], dx, dw, db)``."""
+    _req(x, F32, "x", 2)
+    _req(w, F32, "w", 2)
+    b, k = x.shape
+    n = w.shape[0]
+    dev = x.device
+    logits = torch.empty(b, n, dtype=F32, device=dev)
+    loss = torch.empty(1, dtype=F32, device=dev)
+    correct = torch.empty(1, dtype=torch.int32, device=dev)
+    dx = torch.empty(b, k, dtype=F32, device=dev)
+    dw = torch.empty(n, k, dtype=F32, device=dev)
+    db = torch.empty(n, dtype=F32, device=dev)
+    ws = torch.empty(lib().fc_train_workspace_elems(b, k, n), dtype=F32, device=dev)
+    lib().fc_train_f32(x.data_ptr(), w.data_ptr(), bias.data_ptr(), target.data_ptr(),
+                       logits.data_ptr(), loss.data_ptr(), correct.data_ptr(), dx.data_ptr(),
+                       dw.data_ptr(), db.data_ptr(), ws.data_ptr(), b, k, n, _stream())
+    return logits, loss, correct, dx, dw, db
+
+
+def linear_fwd_f32(x, w, bias):
+    _req(x, F32, "x", 2)
+    b, k = x.shape
+    n = w.shape[0]
+    out = torch.empty(b, n, dtype=F32, device=x.device)
+    lib().linear_fwd_f32(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), b, k, n, _stream())
+    return out
+
+
+def nchw_to_nhwc4_f32(x):
+    _req(x, F32, "x", 4)
+    b = x.shape[0]
+    out = torch.empty(b, 32, 32, 4, dtype=F32, device=x.device)
+    lib().nchw_to_nhwc4_f32(x.data_ptr(), out.data_ptr(), b, _stream())
+    return out

@@ -1,0 +1,199 @@
+"""Numerics of the fp32-activation kernels (the reference's precision, --dtype fp32) against
+PyTorch references computed in float64 from the same fp32 inputs: F.conv2d,
+torch.nn.grad.conv2d_input / conv2d_weight, F.batch_norm + relu, F.max_pool2d, F.linear +
+F.cross_entropy.  Tolerance 1e-4 of the reference's scale (the kernels sum exact fp32 products
+in fp32).  Shapes: the eight VGG-11 conv layers at batch 2, 64 and 256."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+# (cin, cout, hw) of VGG-11 conv2..conv8, then the 128 -> 128 shape of VGG13+
+LAYERS = [(64, 128, 16), (128, 256, 8), (256, 256, 8), (256, 512, 4), (512, 512, 4), (512, 512, 2),
+          (128, 128, 16)]
+BATCHES = [2, 64, 256]
+
+
+def native():
+    from distributed_machine_learning_amd.ops import native as n
+    n.lib()
+    return n
+
+
+def rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def nchw(x):
+    return x.double().permute(0, 3, 1, 2).contiguous()
+
+
+def check(name, got, ref, tol=1e-4):
+    got, ref = got.double(), ref.double()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    scale = float(ref.abs().max().clamp_min(1e-30))
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f"{name}: max err {err:.3g} vs scale {scale:.3g} (rel {err / scale:.3g})"
+
+
+@pytest.mark.parametrize("batch", BATCHES)
+@pytest.mark.parametrize("cin,cout,hw", LAYERS)
+def test_conv3x3_fwd_f32(batch, cin, cout, hw):
+    n = native()
+    x = rand(batch, hw, hw, cin, seed=1)
+    w = rand(cout, 3, 3, cin, scale=(2.0 / (9 * cin)) ** 0.5, seed=2)
+    b = rand(cout, scale=0.1, seed=3)
+    ref = F.conv2d(nchw(x), nchw(w), b.double(), padding=1)
+    check(f"fwd {cin}->{cout}@{hw} B{batch}", nchw(n.conv3x3_fwd_f32(x, w, b, relu=False)), ref)
+    check(f"fwd+relu {cin}->{cout}@{hw} B{batch}", nchw(n.conv3x3_fwd_f32(x, w, b, relu=True)),
+          ref.relu())
+    for tile in (64, 128):
+        if tile == 128 and cout % 128:
+            continue
+        check(f"fwd tile{tile}", nchw(n.conv3x3_fwd_f32(x, w, b, relu=False, tile=tile)), ref)
+
+
+@pytest.mark.parametrize("batch", BATCHES)
+@pytest.mark.parametrize("cin,cout,hw", LAYERS)
+def test_conv3x3_dgrad_f32(batch, cin, cout, hw):
+    n = native()
+    dy = rand(batch, hw, hw, cout, seed=4)
+    w = rand(cout, 3, 3, cin, scale=(2.0 / (9 * cin)) ** 0.5, seed=5)
+    mask = rand(batch, hw, hw, cin, seed=6)
+    wd = n.repack_dgrad_f32(w)
+    ref = torch.nn.grad.conv2d_input((batch, cin, hw, hw), nchw(w), nchw(dy), padding=1)
+    check(f"dgrad {cin}<-{cout}@{hw} B{batch}", nchw(n.conv3x3_dgrad_f32(dy, wd)), ref)
+    check("dgrad+mask", nchw(n.conv3x3_dgrad_f32(dy, wd, relu_mask=mask)), ref * (nchw(mask) > 0))
+
+
+@pytest.mark.parametrize("batch", BATCHES)
+@pytest.mark.parametrize("cin,cout,hw", LAYERS)
+def test_conv3x3_wgrad_f32(batch, cin, cout, hw):
+    n = native()
+    x = rand(batch, hw, hw, cin, seed=7)
+    dy = rand(batch, hw, hw, cout, seed=8)
+    ref = torch.nn.grad.conv2d_weight(nchw(x), (cout, cin, 3, 3), nchw(dy), padding=1)
+    check(f"wgrad {cin}->{cout}@{hw} B{batch}", nchw(n.conv3x3_wgrad_f32(x, dy)), ref)
+    if batch == 64:
+        for splits in (1, 3):
+            check(f"wgrad splits {splits}", nchw(n.conv3x3_wgrad_f32(x, dy, splits=splits)), ref)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 64, 256])
+def test_conv1_f32(batch):
+    n = native()
+    x = rand(batch, 3, 32, 32, seed=9)
+    x4 = n.nchw_to_nhwc4_f32(x)
+    assert torch.equal(x4[..., :3], x.permute(0, 2, 3, 1)) and bool((x4[..., 3] == 0).all())
+    w = rand(64, 3, 3, 3, scale=(2.0 / 27) ** 0.5, seed=10)
+    b = rand(64, scale=0.1, seed=11)
+    ref = F.conv2d(x.double(), nchw(w), b.double(), padding=1)
+    check("conv1 fwd", nchw(n.conv1_fwd_f32(x4, w, b, relu=False)), ref)
+    check("conv1 fwd+relu", nchw(n.conv1_fwd_f32(x4, w, b, relu=True)), ref.relu())
+    dy = rand(batch, 32, 32, 64, seed=12)
+    dw, db = n.conv1_wgrad_f32(x4, dy)
+    check("conv1 dW", nchw(dw), torch.nn.grad.conv2d_weight(x.double(), (64, 3, 3, 3), nchw(dy),
+                                                           padding=1))
+    check("conv1 db", db, dy.double().sum((0, 1, 2)))
+
+
+@pytest.mark.parametrize("rows,c", [(2 * 32 * 32, 64), (256 * 16 * 16, 128), (256 * 4 * 4, 512),
+                                    (8, 512)])
+def test_bn_relu_f32(rows, c):
+    n = native()
+    x = rand(rows, c, seed=13) * 2 + 0.5
+    gamma = rand(c, seed=14) * 0.2 + 1
+    beta = rand(c, scale=0.3, seed=15)
+    rm = torch.zeros(c, device=DEV)
+    rv = torch.ones(c, device=DEV)
+    y, mean, rstd = n.bn_relu_fwd_train_f32(x, gamma, beta, rm, rv)
+    x64, g64, b64 = x.double(), gamma.double(), beta.double()
+    m64, v64 = x64.mean(0), x64.var(0, unbiased=False)
+    r64 = (v64 + 1e-5).rsqrt()
+    xh = (x64 - m64) * r64
+    check("bn fwd", y, (g64 * xh + b64).relu())
+    check("bn save_mean", mean, m64, tol=1e-5)
+    check("bn save_rstd", rstd, r64, tol=1e-5)
+    check("bn running_mean", rm, 0.1 * m64)
+    check("bn running_var", rv, 0.9 + 0.1 * x64.var(0, unbiased=True))
+    # backward with the ReLU decisions the kernel made (an activation within rounding of zero can
+    # fall on either side in fp32 and in float64; the formulas are what is being checked)
+    dy = rand(rows, c, seed=16)
+    dx, dgamma, dbeta = n.bn_relu_bwd_f32(x, dy.clone(), gamma, beta, mean, rstd)
+    g = dy.double() * (y > 0)
+    db_ref, dg_ref = g.sum(0), (g * xh).sum(0)
+    check("bn dbeta", dbeta, db_ref)
+    check("bn dgamma", dgamma, dg_ref)
+    check("bn dx", dx, g64 * r64 * (g - db_ref / rows - xh * dg_ref / rows))
+    ye = n.bn_relu_fwd_eval_f32(x, gamma, beta, rm, rv)
+    check("bn eval", ye, (g64 * (x64 - rm.double()) * (rv.double() + 1e-5).rsqrt() + b64).relu())
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_bn_statistics_survive_a_large_mean(dtype):
+    """A channel whose mean is 100x its standard deviation: E[x^2] - E[x]^2 in fp32 would lose
+    ~13 bits of the variance; the kernels sum around a per-channel sample instead."""
+    n = native()
+    rows, c = 64 * 8 * 8, 128
+    x = rand(rows, c, seed=17)
+    x[:, ::2] += 100.0
+    x[:, 1::4] *= 1e-2
+    x[:, 1::4] += 3.0
+    gamma, beta = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+    if dtype == "bf16":
+        xs = x.to(torch.bfloat16)
+        y, mean, rstd = n.bn_relu_fwd_train(xs, gamma, beta)
+        xs = xs.double()
+    else:
+        y, mean, rstd = n.bn_relu_fwd_train_f32(x, gamma, beta)
+        xs = x.double()
+    var = xs.var(0, unbiased=False)
+    check("mean", mean, xs.mean(0), tol=1e-6)
+    got_var = 1.0 / rstd.double() ** 2 - 1e-5
+    rel = ((got_var - var).abs() / var).max()
+    assert float(rel) < 1e-4, float(rel)
+
+
+@pytest.mark.parametrize("batch,hw,c", [(2, 32, 64), (64, 8, 256), (256, 2, 512)])
+def test_maxpool_f32(batch, hw, c):
+    n = native()
+    x = rand(batch, hw, hw, c, seed=18)
+    y = n.maxpool2x2_fwd_f32(x)
+    xr = nchw(x).requires_grad_(True)
+    yr = F.max_pool2d(xr, 2)
+    assert torch.equal(nchw(y), yr.detach())
+    dy = rand(batch, hw // 2, hw // 2, c, seed=19)
+    yr.backward(nchw(dy))
+    assert torch.equal(nchw(n.maxpool2x2_bwd_f32(x, dy)), xr.grad)
+    xp = x.relu()
+    got = n.maxpool2x2_bwd_f32(xp, dy, relu_mask=True)
+    xr2 = nchw(xp).requires_grad_(True)
+    F.max_pool2d(xr2, 2).backward(nchw(dy))
+    assert torch.equal(nchw(got), xr2.grad * (nchw(xp) > 0))
+
+
+@pytest.mark.parametrize("batch", [1, 7, 64, 256])
+def test_classifier_f32(batch):
+    n = native()
+    x = rand(batch, 512, seed=20).relu()
+    w = rand(10, 512, scale=0.05, seed=21)
+    b = rand(10, scale=0.1, seed=22)
+    t = torch.randint(0, 10, (batch,), generator=torch.Generator().manual_seed(23)).to(DEV)
+    xr = x.double().clone().requires_grad_(True)
+    wr = w.double().clone().requires_grad_(True)
+    br = b.double().clone().requires_grad_(True)
+    lr = F.linear(xr, wr, br)
+    loss_ref = F.cross_entropy(lr, t)
+    loss_ref.backward()
+    logits, loss, correct, dx, dw, db = n.fc_train_f32(x, w, b, t)
+    check("logits", logits, lr.detach())
+    check("logits(eval)", n.linear_fwd_f32(x, w, b), lr.detach())
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    assert int(correct) == int((lr.argmax(1) == t).sum())
+    check("dx", dx, xr.grad)
+    check("dW", dw, wr.grad)
+    check("db", db, br.grad)
+    check("column_sum", n.column_sum_f32(x.view(batch, 512)), x.double().sum(0))
