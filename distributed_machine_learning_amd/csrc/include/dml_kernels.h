@@ -295,7 +295,8 @@ void nchw_to_nhwc4(const float* x, float* out, int batch, hipStream_t stream);
 // `mask` (EPI_MASK) has the output's shape.  No workspace: the reduction is never split.
 void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bias,
                        const float* mask, ConvShape s, ConvEpilogue epi, hipStream_t stream,
-                       int force_tile = 0 /* tuning: 128 or 64 */);
+                       int force_tile = 0 /* tuning: 128 or 64 */,
+                       int force_pm = -1 /* tuning: position-major tiles off / on */);
 // wd[cin][8 - tap][cout] = wf[cout][tap][cin]
 void repack_dgrad_weights_f32(const float* wf, float* wd, int cout, int cin, hipStream_t stream);
 // dw[cout][9][cin] = sum_p dy[p][cout] * x[p (+) tap][cin].  The pixel range is split over
@@ -303,8 +304,8 @@ void repack_dgrad_weights_f32(const float* wf, float* wd, int cout, int cin, hip
 // partial result to `slab` (splits * cout*9*cin floats) and the caller sums them
 // (sum_slabs_batch), with one split `dw` is written directly.
 void conv3x3_wgrad_f32(const float* x, const float* dy, float* dw, ConvShape s, float* slab,
-                       hipStream_t stream, int force_splits = 0);
-int conv3x3_wgrad_f32_splits(ConvShape s, int force_splits = 0);
+                       hipStream_t stream, int force_splits = 0, int force_pm = -1);
+int conv3x3_wgrad_f32_splits(ConvShape s, int force_splits = 0, int force_pm = -1);
 // First layer on fp32: x [B,32,32,4] (3 channels + zero pad), w the master weights
 // [64][9][3], y = relu?(conv + bias) [B,32,32,64].
 void conv1_fprop_f32(const float* x, const float* w, const float* bias, float* y, int batch,

@@ -42,17 +42,26 @@ int log2_exact(int v) {
 // with the row's eight 16-byte slots XOR-permuted by (row & 7); a lane reads its operand for
 // four MFMA steps as one ds_read_b128: lane half h takes reduction elements 8q+4h .. 8q+4h+3,
 // so step t of group q sums elements 8q+t and 8q+4+t - the same pairing on both operands.
+//
+// Two row orders.  Pixel-major: a tile is BM consecutive pixels (b,h,w) and every tap is
+// multiplied, padded rows contributing zeros.  Position-major (PM, small maps): a tile is BM
+// images at ONE spatial position, so a tap that falls outside the map does so for the whole
+// tile and its K steps are skipped - at 2x2 that is 5 of 9 taps, at 4x4 31 % and at 8x8 16 %
+// of the multiply work, which is what this kernel's time consists of.
 struct IgemmParams {
     const float* x;
     const float* w;
     float* y;
     const float* bias;
     const float* mask;
-    int M, N, cin, hw, log_hw, epi;
+    int M, N, cin, hw, log_hw, batch;
 };
 
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void conv3x3_igemm_f32_kernel(IgemmParams p) {
+// (waves_per_eu: without the cap hipcc aims for 7 waves per SIMD on the 64 x 64 variant and
+// spills the staging registers to scratch to get there; the LDS tiles allow 5 blocks per CU)
+template <int MT, int NT, bool PM, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
+void conv3x3_igemm_f32_kernel(IgemmParams p) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
     constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;     // float4 loads per thread and chunk
     __shared__ __attribute__((aligned(16))) float As[2][BM * kBK];
@@ -61,8 +70,30 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_f32_kernel(IgemmParams p) {
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = p.N / BN;
-    const int m0 = (blockIdx.x / ntiles) * BM, n0 = (blockIdx.x % ntiles) * BN;
-    const int hw = p.hw, cin = p.cin;
+    const int mt = blockIdx.x / ntiles, n0 = (blockIdx.x % ntiles) * BN;
+    const int hw = p.hw, cin = p.cin, npix = hw * hw;
+    // PM: block = (position, image tile); pixel-major: block = pixel tile
+    const int btiles = PM ? (p.batch + BM - 1) / BM : 1;
+    const int pos = PM ? mt / btiles : 0;
+    const int row0 = PM ? (mt % btiles) * BM : mt * BM;      // first image / first pixel
+    auto row_m = [&](int row) { return PM ? (row0 + row) * npix + pos : row0 + row; };
+    auto row_ok = [&](int row) { return PM ? row0 + row < p.batch : row0 + row < p.M; };
+
+    // taps this block multiplies, 4 bits each
+    unsigned long long taps = 0x876543210ull;
+    int ntaps = 9;
+    if (PM) {
+        const int ph = pos >> p.log_hw, pw = pos & (hw - 1);
+        taps = 0;
+        ntaps = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int dh = t / 3 - 1, dw = t % 3 - 1;
+            if ((unsigned)(ph + dh) < (unsigned)hw && (unsigned)(pw + dw) < (unsigned)hw) {
+                taps |= (unsigned long long)t << (4 * ntaps);
+                ++ntaps;
+            }
+        }
+    }
 
     // the rows this thread stages are the same for every chunk
     int a_h[LA], a_w[LA];
@@ -71,8 +102,8 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_f32_kernel(IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int idx = tid + 256 * i, row = idx >> 3;
-        const int m = m0 + row;
-        a_ok[i] = m < p.M;
+        const int m = row_m(row);
+        a_ok[i] = row_ok(row);
         a_w[i] = m & (hw - 1);
         a_h[i] = (m >> p.log_hw) & (hw - 1);
         a_base[i] = (long)m * cin + (idx & 7) * 4;
@@ -83,33 +114,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_f32_kernel(IgemmParams p) {
         const int idx = tid + 256 * i, row = idx >> 3;
         b_base[i] = (long)(n0 + row) * 9 * cin + (idx & 7) * 4;
     }
-    const int chunks = cin / kBK, steps = 9 * chunks;
-    float4 ra[LA], rb[LB];
-    auto fetch = [&](int step) {
-        const int tap = step / chunks, c0 = (step - tap * chunks) * kBK;
-        const int dh = tap / 3 - 1, dw = tap % 3 - 1;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const bool ok = a_ok[i] && (unsigned)(a_h[i] + dh) < (unsigned)hw &&
-                            (unsigned)(a_w[i] + dw) < (unsigned)hw;
-            ra[i] = ok ? *(const float4*)(p.x + a_base[i] + (long)(dh * hw + dw) * cin + c0)
-                       : float4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i) rb[i] = *(const float4*)(p.w + b_base[i] + (long)tap * cin + c0);
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, slot = (idx & 7) ^ (row & 7);
-            *(float4*)(&As[buf][row * kBK + slot * 4]) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, slot = (idx & 7) ^ (row & 7);
-            *(float4*)(&Bs[buf][row * kBK + slot * 4]) = rb[i];
-        }
-    };
+    const int chunks = cin / kBK, steps = ntaps * chunks;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -119,53 +124,101 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_f32_kernel(IgemmParams p) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
-    fetch(0);
-    stash(0);
+    // Staging registers of the chunk after the one being multiplied.  Loads are branch-free
+    // (a row outside the map or the tensor reads a safe address and is zeroed) and issued
+    // unconditionally - the last iteration re-loads the last chunk and nobody reads it.
+    float4 ra[LA], rb[LB];
+    int ld_tap = 0, ld_chunk = 0;           // position of the next chunk to load
+#define DML_F32_FETCH()                                                                        \
+    {                                                                                          \
+        const int ti = ld_tap < ntaps ? ld_tap : ntaps - 1;                                    \
+        const int tap = (int)((taps >> (4 * ti)) & 15);                                        \
+        const int dh = tap / 3 - 1, dw = tap % 3 - 1;                                          \
+        const int c0 = ld_chunk * kBK;                                                         \
+        const long shift = (long)(dh * hw + dw) * cin + c0;                                    \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                       \
+            const bool ok = a_ok[i] && (PM || ((unsigned)(a_h[i] + dh) < (unsigned)hw &&       \
+                                               (unsigned)(a_w[i] + dw) < (unsigned)hw));       \
+            const float4 v = *(const float4*)(ok ? p.x + a_base[i] + shift : p.x);             \
+            ra[i] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};                                       \
+        }                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i)                                         \
+            rb[i] = *(const float4*)(p.w + b_base[i] + (long)tap * cin + c0);                  \
+        if (++ld_chunk == chunks) { ld_chunk = 0; ++ld_tap; }                                  \
+    }
+#define DML_F32_STASH(buf)                                                                     \
+    {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                       \
+            const int idx = tid + 256 * i, row = idx >> 3, slot = (idx & 7) ^ (row & 7);       \
+            *(float4*)(&As[buf][row * kBK + slot * 4]) = ra[i];                                \
+        }                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                       \
+            const int idx = tid + 256 * i, row = idx >> 3, slot = (idx & 7) ^ (row & 7);       \
+            *(float4*)(&Bs[buf][row * kBK + slot * 4]) = rb[i];                                \
+        }                                                                                      \
+    }
+#define DML_F32_FRAGS(buf, q, FA, FB)                                                          \
+    {                                                                                          \
+        _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                       \
+            const int row = wm * 32 * MT + a * 32 + r;                                         \
+            FA[a] = *(const float4*)(&As[buf][row * kBK + (((2 * (q) + h) ^ (row & 7)) * 4)]); \
+        }                                                                                      \
+        _Pragma("unroll") for (int b = 0; b < NT; ++b) {                                       \
+            const int row = wn * 32 * NT + b * 32 + r;                                         \
+            FB[b] = *(const float4*)(&Bs[buf][row * kBK + (((2 * (q) + h) ^ (row & 7)) * 4)]); \
+        }                                                                                      \
+    }
+
+    DML_F32_FETCH();
+    DML_F32_STASH(0);
     __syncthreads();
     for (int step = 0; step < steps; ++step) {
         const int buf = step & 1;
-        if (step + 1 < steps) fetch(step + 1);
+        DML_F32_FETCH();                    // in flight behind this chunk's MFMAs
+        // Operand fragments one group ahead of the MFMAs that use them.  The scheduling
+        // barriers pin that order: left alone, hipcc sinks the global loads to the end of the
+        // chunk and reads each fragment right before its first use, exposing both latencies
+        // on every group (one wave per SIMD has nothing else to run meanwhile).
+        float4 fa[2][MT], fb[2][NT];
+        DML_F32_FRAGS(buf, 0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 fa[MT], fb[NT];
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const int row = wm * 32 * MT + a * 32 + r;
-                fa[a] = *(const float4*)(&As[buf][row * kBK + (((2 * q + h) ^ (row & 7)) * 4)]);
-            }
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int row = wn * 32 * NT + b * 32 + r;
-                fb[b] = *(const float4*)(&Bs[buf][row * kBK + (((2 * q + h) ^ (row & 7)) * 4)]);
-            }
+            if (q < 3) DML_F32_FRAGS(buf, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
                     for (int b = 0; b < NT; ++b)
-                        acc[a][b] = mfma32(((const float*)&fa[a])[t], ((const float*)&fb[b])[t],
-                                           acc[a][b]);
+                        acc[a][b] = mfma32(((const float*)&fa[q & 1][a])[t],
+                                           ((const float*)&fb[q & 1][b])[t], acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (step + 1 < steps) stash(buf ^ 1);
+        DML_F32_STASH(buf ^ 1);
         __syncthreads();
     }
+#undef DML_F32_FETCH
+#undef DML_F32_STASH
+#undef DML_F32_FRAGS
 
     // epilogue: a lane owns column n = .. + r and 16 rows per tile
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const int n = n0 + wn * 32 * NT + b * 32 + r;
-        const float bias = (p.epi == EPI_BIAS || p.epi == EPI_BIAS_RELU) ? p.bias[n] : 0.f;
+        const float bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const int m = m0 + wm * 32 * MT + a * 32 + acc_row(g, h);
-                if (m >= p.M) continue;
+                const int row = wm * 32 * MT + a * 32 + acc_row(g, h);
+                const bool ok = row_ok(row);
+                const long at = (long)(ok ? row_m(row) : 0) * p.N + n;
                 float v = acc[a][b][g] + bias;
-                if (p.epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                if (p.epi == EPI_MASK && !(p.mask[(long)m * p.N + n] > 0.f)) v = 0.f;
-                p.y[(long)m * p.N + n] = v;
+                if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                if (EPI == EPI_MASK) v = p.mask[at] > 0.f ? v : 0.f;
+                if (ok) p.y[at] = v;
             }
         }
     }
@@ -176,16 +229,20 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_f32_kernel(IgemmParams p) {
 // pixel-major in memory and stay so in LDS ([32 pixels][channels]): a lane's A element
 // dy[p = 2s+h][co = r] and B element x[p][ci = r] are plain 4-byte LDS reads, consecutive lanes
 // on consecutive banks.  blockIdx.x = (co tile, ci tile, tap), blockIdx.y = split of the pixels.
+// The pixels are walked in chunks of 32; with PM (small maps) a chunk is 32 images at one
+// spatial position, and the chunks whose position this block's tap shifts off the map are
+// skipped (same saving as in the forward kernel).
 struct WgradParams {
     const float* x;
     const float* dy;
     float* out;          // dw, or the slab of this launch (split s at out + s * slab_stride)
     long slab_stride;
-    int M, cin, cout, hw, log_hw, chunks_per_split;
+    int M, cin, cout, hw, log_hw, chunks_per_split, total_chunks, batch;
 };
 
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(WgradParams p) {
+template <int MT, int NT, bool PM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
+void conv3x3_wgrad_f32_kernel(WgradParams p) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
     constexpr int LA = kBK * BM / 4 / 256, LB = kBK * BN / 4 / 256;
     __shared__ __attribute__((aligned(16))) float Ds[2][kBK * BM];
@@ -198,38 +255,20 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(WgradParams p) {
     const int tile = blockIdx.x / 9;
     const int co0 = (tile / ci_tiles) * BM, ci0 = (tile % ci_tiles) * BN;
     const int dh = tap / 3 - 1, dw = tap % 3 - 1;
-    const int hw = p.hw;
-    const int total_chunks = (p.M + kBK - 1) / kBK;
+    const int hw = p.hw, npix = hw * hw;
     const int c_begin = blockIdx.y * p.chunks_per_split;
     int c_end = c_begin + p.chunks_per_split;
-    if (c_end > total_chunks) c_end = total_chunks;
-
-    float4 rd[LA], rx[LB];
-    auto fetch = [&](int chunk) {
-        const int p0 = chunk * kBK;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int idx = tid + 256 * i, px = idx / (BM / 4), c4 = idx % (BM / 4);
-            const int m = p0 + px;
-            rd[i] = m < p.M ? *(const float4*)(p.dy + (long)m * p.cout + co0 + c4 * 4)
-                            : float4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            const int idx = tid + 256 * i, px = idx / (BN / 4), c4 = idx % (BN / 4);
-            const int m = p0 + px;
-            const int w_ = m & (hw - 1), h_ = (m >> p.log_hw) & (hw - 1);
-            const bool ok = m < p.M && (unsigned)(h_ + dh) < (unsigned)hw &&
-                            (unsigned)(w_ + dw) < (unsigned)hw;
-            rx[i] = ok ? *(const float4*)(p.x + (long)(m + dh * hw + dw) * p.cin + ci0 + c4 * 4)
-                       : float4{0.f, 0.f, 0.f, 0.f};
-        }
+    if (c_end > p.total_chunks) c_end = p.total_chunks;
+    // PM: chunk c = 32 images (c / npix) at position c % npix
+    auto chunk_live = [&](int c) {
+        if (!PM) return true;
+        const int pos = c % npix;
+        return (unsigned)((pos >> p.log_hw) + dh) < (unsigned)hw &&
+               (unsigned)((pos & (hw - 1)) + dw) < (unsigned)hw;
     };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < LA; ++i) *(float4*)(&Ds[buf][(tid + 256 * i) * 4]) = rd[i];
-#pragma unroll
-        for (int i = 0; i < LB; ++i) *(float4*)(&Xs[buf][(tid + 256 * i) * 4]) = rx[i];
+    auto next_live = [&](int c) {
+        while (c < c_end && !chunk_live(c)) ++c;
+        return c;
     };
 
     f32x16 acc[MT][NT];
@@ -240,29 +279,77 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(WgradParams p) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
-    if (c_begin < c_end) {
-        fetch(c_begin);
-        stash(0);
+    float4 rd[LA], rx[LB];
+#define DML_F32_WFETCH(chunk)                                                                  \
+    {                                                                                          \
+        const int cc = (chunk) < c_end ? (chunk) : c_begin;      /* unused past the end */     \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                       \
+            const int idx = tid + 256 * i, px = idx / (BM / 4), c4 = idx % (BM / 4);           \
+            const int m = PM ? ((cc / npix) * kBK + px) * npix + cc % npix : cc * kBK + px;    \
+            const bool ok = PM ? (cc / npix) * kBK + px < p.batch : m < p.M;                   \
+            const float4 v = *(const float4*)(ok ? p.dy + (long)m * p.cout + co0 + c4 * 4 : p.dy); \
+            rd[i] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};                                       \
+        }                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                       \
+            const int idx = tid + 256 * i, px = idx / (BN / 4), c4 = idx % (BN / 4);           \
+            const int m = PM ? ((cc / npix) * kBK + px) * npix + cc % npix : cc * kBK + px;    \
+            const int w_ = m & (hw - 1), h_ = (m >> p.log_hw) & (hw - 1);                      \
+            const bool ok = (PM ? (cc / npix) * kBK + px < p.batch : m < p.M) &&               \
+                            (unsigned)(h_ + dh) < (unsigned)hw && (unsigned)(w_ + dw) < (unsigned)hw; \
+            const float4 v = *(const float4*)(                                                 \
+                ok ? p.x + (long)(m + dh * hw + dw) * p.cin + ci0 + c4 * 4 : p.x);             \
+            rx[i] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};                                       \
+        }                                                                                      \
     }
+#define DML_F32_WSTASH(buf)                                                                    \
+    {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i)                                         \
+            *(float4*)(&Ds[buf][(tid + 256 * i) * 4]) = rd[i];                                 \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i)                                         \
+            *(float4*)(&Xs[buf][(tid + 256 * i) * 4]) = rx[i];                                 \
+    }
+
+    int chunk = next_live(c_begin);
+    DML_F32_WFETCH(chunk);
+    DML_F32_WSTASH(0);
     __syncthreads();
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        const int buf = (chunk - c_begin) & 1;
-        if (chunk + 1 < c_end) fetch(chunk + 1);
-#pragma unroll
-        for (int s = 0; s < kBK / 2; ++s) {
-            float fa[MT], fb[NT];
-#pragma unroll
-            for (int a = 0; a < MT; ++a) fa[a] = Ds[buf][(2 * s + h) * BM + wm * 32 * MT + a * 32 + r];
-#pragma unroll
-            for (int b = 0; b < NT; ++b) fb[b] = Xs[buf][(2 * s + h) * BN + wn * 32 * NT + b * 32 + r];
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b) acc[a][b] = mfma32(fa[a], fb[b], acc[a][b]);
+    int buf = 0;
+    while (chunk < c_end) {
+        const int nxt = next_live(chunk + 1);
+        DML_F32_WFETCH(nxt);
+        // fragments of four MFMA steps at a time, one group ahead (order pinned, see igemm)
+        float fa[2][4][MT], fb[2][4][NT];
+#define DML_F32_WFRAGS(grp, F)                                                                 \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                        \
+            const int prow = 2 * (4 * (grp) + u) + h;                                          \
+            _Pragma("unroll") for (int a = 0; a < MT; ++a)                                     \
+                fa[F][u][a] = Ds[buf][prow * BM + wm * 32 * MT + a * 32 + r];                  \
+            _Pragma("unroll") for (int b = 0; b < NT; ++b)                                     \
+                fb[F][u][b] = Xs[buf][prow * BN + wn * 32 * NT + b * 32 + r];                  \
         }
-        if (chunk + 1 < c_end) stash(buf ^ 1);
+        DML_F32_WFRAGS(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int grp = 0; grp < kBK / 8; ++grp) {
+            if (grp + 1 < kBK / 8) DML_F32_WFRAGS(grp + 1, (grp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = mfma32(fa[grp & 1][u][a], fb[grp & 1][u][b], acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef DML_F32_WFRAGS
+        DML_F32_WSTASH(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
+        chunk = nxt;
     }
+#undef DML_F32_WFETCH
+#undef DML_F32_WSTASH
     float* out = p.out + (long)blockIdx.y * p.slab_stride;
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -395,15 +482,26 @@ __global__ __launch_bounds__(256) void conv1_wgrad_f32_kernel(
         out[i] = red[i] + red[2048 + i] + red[4096 + i] + red[6144 + i];
 }
 
+// out[i] = sum over the blocks' partials, i = (co, k) of 64 x 32: a block of 256 threads owns
+// 16 outputs, 16 threads per output each summing every 16th partial, folded through LDS in a
+// fixed order.
 __global__ __launch_bounds__(256) void conv1_wgrad_f32_fold_kernel(
     const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db, int nblocks) {
-    const int i = blockIdx.x * 256 + threadIdx.x;       // (co, k) of 64 x 32
-    if (i >= 2048) return;
+    __shared__ float red[16][17];
+    const int ol = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + ol;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += ws[(long)b * 2048 + i];
-    const int co = i >> 5, k = i & 31;
-    if (k < 27) dw[co * 27 + k] = s;
-    else if (k == 27 && db) db[co] = s;
+    for (int b = part; b < nblocks; b += 16) s += ws[(long)b * 2048 + i];
+    red[part][ol] = s;
+    __syncthreads();
+    if (part == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][ol];
+        const int co = i >> 5, k = i & 31;
+        if (k < 27) dw[co * 27 + k] = t;
+        else if (k == 27 && db) db[co] = t;
+    }
 }
 
 // ----------------------------------------------------------------------------- helpers
@@ -439,21 +537,54 @@ void check_shape(const ConvShape& s, const char* who) {
 
 }  // namespace
 
+namespace {
+template <int MT, int NT, bool PM>
+void launch_igemm(const IgemmParams& p, ConvEpilogue epi, unsigned blocks, hipStream_t stream) {
+    switch (epi) {
+        case EPI_NONE:
+            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_NONE>), dim3(blocks),
+                               dim3(256), 0, stream, p);
+            break;
+        case EPI_BIAS:
+            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_BIAS>), dim3(blocks),
+                               dim3(256), 0, stream, p);
+            break;
+        case EPI_BIAS_RELU:
+            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_BIAS_RELU>), dim3(blocks),
+                               dim3(256), 0, stream, p);
+            break;
+        case EPI_MASK:
+            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_MASK>), dim3(blocks),
+                               dim3(256), 0, stream, p);
+            break;
+    }
+}
+}  // namespace
+
 void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bias,
                        const float* mask, ConvShape s, ConvEpilogue epi, hipStream_t stream,
-                       int force_tile) {
+                       int force_tile, int force_pm) {
     check_shape(s, "conv3x3_igemm_f32");
     if (!x || !w || !y) throw std::invalid_argument("conv3x3_igemm_f32: null tensor");
     if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias)
         throw std::invalid_argument("conv3x3_igemm_f32: bias missing");
     if (epi == EPI_MASK && !mask) throw std::invalid_argument("conv3x3_igemm_f32: mask missing");
+    if ((int)epi < 0 || (int)epi > 3) throw std::invalid_argument("conv3x3_igemm_f32: bad epilogue");
     IgemmParams p;
     p.x = x; p.w = w; p.y = y; p.bias = bias; p.mask = mask;
     p.M = s.batch * s.hw * s.hw; p.N = s.cout; p.cin = s.cin; p.hw = s.hw;
-    p.log_hw = log2_exact(s.hw); p.epi = (int)epi;
+    p.log_hw = log2_exact(s.hw); p.batch = s.batch;
+    // position-major tiles (padded taps skipped) on the small maps, when a tile of images fills
+    bool pm = s.hw <= 8 && s.hw >= 2 && s.batch >= 64;
+    if (force_pm == 0) pm = false;
+    else if (force_pm == 1) pm = s.hw >= 2;
+    else if (force_pm != -1) throw std::invalid_argument("conv3x3_igemm_f32: pm must be -1, 0 or 1");
     // 128 x 128 tiles where they still give every CU a block, 64 x 64 tiles otherwise
-    const long big_blocks = (long)((p.M + 127) / 128) * (p.N / 128);
-    bool big = p.N % 128 == 0 && big_blocks >= 256;
+    auto blocks_for = [&](int tile) {
+        const long mt = pm ? (long)s.hw * s.hw * ((s.batch + tile - 1) / tile) : (p.M + tile - 1) / tile;
+        return mt * (p.N / tile);
+    };
+    bool big = p.N % 128 == 0 && blocks_for(128) >= 256 && (!pm || s.batch >= 128);
     if (force_tile == 128) {
         if (p.N % 128) throw std::invalid_argument("conv3x3_igemm_f32: 128 tiles need cout % 128 == 0");
         big = true;
@@ -462,12 +593,11 @@ void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bi
     } else if (force_tile != 0) {
         throw std::invalid_argument("conv3x3_igemm_f32: tile must be 64 or 128");
     }
-    if (big)
-        hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<2, 2>), dim3((unsigned)big_blocks), dim3(256), 0,
-                           stream, p);
-    else
-        hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<1, 1>),
-                           dim3((unsigned)(((p.M + 63) / 64) * (p.N / 64))), dim3(256), 0, stream, p);
+    const unsigned blocks = (unsigned)blocks_for(big ? 128 : 64);
+    if (big && pm) launch_igemm<2, 2, true>(p, epi, blocks, stream);
+    else if (big) launch_igemm<2, 2, false>(p, epi, blocks, stream);
+    else if (pm) launch_igemm<1, 1, true>(p, epi, blocks, stream);
+    else launch_igemm<1, 1, false>(p, epi, blocks, stream);
 }
 
 void repack_dgrad_weights_f32(const float* wf, float* wd, int cout, int cin, hipStream_t stream) {
@@ -478,35 +608,43 @@ void repack_dgrad_weights_f32(const float* wf, float* wd, int cout, int cin, hip
 }
 
 namespace {
-struct WgradPlan { int tiles, splits, chunks_per_split; bool wide; };
+struct WgradPlan { int tiles, splits, chunks_per_split, total_chunks; bool wide, pm; };
 
-WgradPlan plan_wgrad(const ConvShape& s, int force_splits) {
+WgradPlan plan_wgrad(const ConvShape& s, int force_splits, int force_pm) {
     WgradPlan pl;
     pl.wide = s.cin % 128 == 0;
     if (s.cout % 128) throw std::invalid_argument("conv3x3_wgrad_f32: cout must be a multiple of 128");
     pl.tiles = (s.cout / 128) * (s.cin / (pl.wide ? 128 : 64));
-    const int chunks = (s.batch * s.hw * s.hw + kBK - 1) / kBK;
+    pl.pm = s.hw <= 8 && s.hw >= 2 && s.batch >= kBK;
+    if (force_pm == 0) pl.pm = false;
+    else if (force_pm == 1) pl.pm = s.hw >= 2;
+    const int npix = s.hw * s.hw;
+    const int chunks = pl.pm ? npix * ((s.batch + kBK - 1) / kBK) : (s.batch * npix + kBK - 1) / kBK;
+    pl.total_chunks = chunks;
     // about two blocks per CU, at least four chunks of pixels per block
     int splits = force_splits > 0 ? force_splits : (512 + pl.tiles * 9 - 1) / (pl.tiles * 9);
     const int max_splits = chunks / 4 > 0 ? chunks / 4 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    pl.chunks_per_split = (chunks + splits - 1) / splits;
-    pl.splits = (chunks + pl.chunks_per_split - 1) / pl.chunks_per_split;
+    int cps = (chunks + splits - 1) / splits;
+    // PM: whole sweeps over the positions per split, so that every split of a tap skips alike
+    if (pl.pm && cps > npix) cps = (cps + npix - 1) / npix * npix;
+    pl.chunks_per_split = cps;
+    pl.splits = (chunks + cps - 1) / cps;
     return pl;
 }
 }  // namespace
 
-int conv3x3_wgrad_f32_splits(ConvShape s, int force_splits) {
+int conv3x3_wgrad_f32_splits(ConvShape s, int force_splits, int force_pm) {
     check_shape(s, "conv3x3_wgrad_f32");
-    return plan_wgrad(s, force_splits).splits;
+    return plan_wgrad(s, force_splits, force_pm).splits;
 }
 
 void conv3x3_wgrad_f32(const float* x, const float* dy, float* dw, ConvShape s, float* slab,
-                       hipStream_t stream, int force_splits) {
+                       hipStream_t stream, int force_splits, int force_pm) {
     check_shape(s, "conv3x3_wgrad_f32");
     if (!x || !dy || !dw) throw std::invalid_argument("conv3x3_wgrad_f32: null tensor");
-    const WgradPlan pl = plan_wgrad(s, force_splits);
+    const WgradPlan pl = plan_wgrad(s, force_splits, force_pm);
     if (pl.splits > 1 && !slab)
         throw std::invalid_argument("conv3x3_wgrad_f32: this shape splits the pixels and needs a slab");
     WgradParams p;
@@ -515,11 +653,16 @@ void conv3x3_wgrad_f32(const float* x, const float* dy, float* dw, ConvShape s, 
     p.slab_stride = (long)s.cout * 9 * s.cin;
     p.M = s.batch * s.hw * s.hw; p.cin = s.cin; p.cout = s.cout; p.hw = s.hw;
     p.log_hw = log2_exact(s.hw); p.chunks_per_split = pl.chunks_per_split;
+    p.total_chunks = pl.total_chunks; p.batch = s.batch;
     const dim3 grid((unsigned)(pl.tiles * 9), (unsigned)pl.splits);
-    if (pl.wide)
-        hipLaunchKernelGGL((conv3x3_wgrad_f32_kernel<2, 2>), grid, dim3(256), 0, stream, p);
+    if (pl.wide && pl.pm)
+        hipLaunchKernelGGL((conv3x3_wgrad_f32_kernel<2, 2, true>), grid, dim3(256), 0, stream, p);
+    else if (pl.wide)
+        hipLaunchKernelGGL((conv3x3_wgrad_f32_kernel<2, 2, false>), grid, dim3(256), 0, stream, p);
+    else if (pl.pm)
+        hipLaunchKernelGGL((conv3x3_wgrad_f32_kernel<2, 1, true>), grid, dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL((conv3x3_wgrad_f32_kernel<2, 1>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv3x3_wgrad_f32_kernel<2, 1, false>), grid, dim3(256), 0, stream, p);
 }
 
 void conv1_fprop_f32(const float* x, const float* w, const float* bias, float* y, int batch,
@@ -547,8 +690,8 @@ void conv1_wgrad_f32(const float* x, const float* dy, float* dw, float* db, int 
     const int nb = conv1_wgrad_blocks(batch);
     hipLaunchKernelGGL(conv1_wgrad_f32_kernel, dim3(nb), dim3(256), 0, stream, x, dy, ws,
                        batch * 1024);
-    hipLaunchKernelGGL(conv1_wgrad_f32_fold_kernel, dim3(8), dim3(256), 0, stream, (const float*)ws,
-                       dw, db, nb);
+    hipLaunchKernelGGL(conv1_wgrad_f32_fold_kernel, dim3(128), dim3(256), 0, stream,
+                       (const float*)ws, dw, db, nb);
 }
 
 void relu_mask_f32(const float* x, const float* mask, float* y, size_t n, hipStream_t stream) {

@@ -507,7 +507,7 @@ def fill_uniform_(t: torch.Tensor, seed: int, scale: float = 1.0) -> torch.Tenso
 F32 = torch.float32
 
 
-def conv3x3_fwd_f32(x, wf, bias=None, relu=True, tile=0):
+def conv3x3_fwd_f32(x, wf, bias=None, relu=True, tile=0, pm=-1):
     _req(x, F32, "x", 4)
     _req(wf, F32, "wf", 4)
     b, h, w, cin = x.shape
@@ -519,7 +519,7 @@ def conv3x3_fwd_f32(x, wf, bias=None, relu=True, tile=0):
     y = torch.empty(b, h, w, cout, dtype=F32, device=x.device)
     epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
     lib().conv3x3_igemm_f32(x.data_ptr(), wf.data_ptr(), y.data_ptr(), _ptr(bias), 0, b, h, cin, cout,
-                            epi, _stream(), tile)
+                            epi, _stream(), tile, pm)
     return y
 
 
@@ -531,7 +531,7 @@ def repack_dgrad_f32(wf):
     return wd
 
 
-def conv3x3_dgrad_f32(dy, wd, relu_mask=None, tile=0):
+def conv3x3_dgrad_f32(dy, wd, relu_mask=None, tile=0, pm=-1):
     _req(dy, F32, "dy", 4)
     _req(wd, F32, "wd", 4)
     b, h, w, cout = dy.shape
@@ -544,11 +544,11 @@ def conv3x3_dgrad_f32(dy, wd, relu_mask=None, tile=0):
         if relu_mask.shape != dx.shape:
             raise ValueError("conv3x3_dgrad_f32: mask shape")
     lib().conv3x3_igemm_f32(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0, _ptr(relu_mask), b, h, cout,
-                            cin, EPI_MASK if relu_mask is not None else EPI_NONE, _stream(), tile)
+                            cin, EPI_MASK if relu_mask is not None else EPI_NONE, _stream(), tile, pm)
     return dx
 
 
-def conv3x3_wgrad_f32(x, dy, splits=0):
+def conv3x3_wgrad_f32(x, dy, splits=0, pm=-1):
     _req(x, F32, "x", 4)
     _req(dy, F32, "dy", 4)
     b, h, w, cin = x.shape
@@ -556,10 +556,10 @@ def conv3x3_wgrad_f32(x, dy, splits=0):
     if tuple(dy.shape[:3]) != (b, h, w) or h != w:
         raise ValueError("conv3x3_wgrad_f32: shape mismatch")
     dw = torch.empty(cout, 3, 3, cin, dtype=F32, device=x.device)
-    n = lib().conv3x3_wgrad_f32_splits(b, h, cin, cout, splits)
+    n = lib().conv3x3_wgrad_f32_splits(b, h, cin, cout, splits, pm)
     slab = torch.empty(n, dw.numel(), dtype=F32, device=x.device)
     lib().conv3x3_wgrad_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), b, h, cin, cout,
-                            slab.data_ptr(), _stream(), splits)
+                            slab.data_ptr(), _stream(), splits, pm)
     if n > 1:       # the engine sums the splits with sum_slabs_batch; here a tensor op does
         dw = slab.sum(dim=0).view_as(dw)
     return dw

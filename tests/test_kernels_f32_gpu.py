@@ -50,10 +50,13 @@ def test_conv3x3_fwd_f32(batch, cin, cout, hw):
     check(f"fwd {cin}->{cout}@{hw} B{batch}", nchw(n.conv3x3_fwd_f32(x, w, b, relu=False)), ref)
     check(f"fwd+relu {cin}->{cout}@{hw} B{batch}", nchw(n.conv3x3_fwd_f32(x, w, b, relu=True)),
           ref.relu())
+    # every tile size in both row orders (pixel-major / position-major with skipped taps)
     for tile in (64, 128):
-        if tile == 128 and cout % 128:
-            continue
-        check(f"fwd tile{tile}", nchw(n.conv3x3_fwd_f32(x, w, b, relu=False, tile=tile)), ref)
+        for pm in (0, 1):
+            if (tile == 128 and cout % 128) or (pm and hw < 2):
+                continue
+            got = n.conv3x3_fwd_f32(x, w, b, relu=False, tile=tile, pm=pm)
+            check(f"fwd tile{tile} pm{pm}", nchw(got), ref)
 
 
 @pytest.mark.parametrize("batch", BATCHES)
@@ -66,7 +69,9 @@ def test_conv3x3_dgrad_f32(batch, cin, cout, hw):
     wd = n.repack_dgrad_f32(w)
     ref = torch.nn.grad.conv2d_input((batch, cin, hw, hw), nchw(w), nchw(dy), padding=1)
     check(f"dgrad {cin}<-{cout}@{hw} B{batch}", nchw(n.conv3x3_dgrad_f32(dy, wd)), ref)
-    check("dgrad+mask", nchw(n.conv3x3_dgrad_f32(dy, wd, relu_mask=mask)), ref * (nchw(mask) > 0))
+    for pm in (0, 1):
+        got = n.conv3x3_dgrad_f32(dy, wd, relu_mask=mask, pm=pm)
+        check(f"dgrad+mask pm{pm}", nchw(got), ref * (nchw(mask) > 0))
 
 
 @pytest.mark.parametrize("batch", BATCHES)
@@ -77,9 +82,13 @@ def test_conv3x3_wgrad_f32(batch, cin, cout, hw):
     dy = rand(batch, hw, hw, cout, seed=8)
     ref = torch.nn.grad.conv2d_weight(nchw(x), (cout, cin, 3, 3), nchw(dy), padding=1)
     check(f"wgrad {cin}->{cout}@{hw} B{batch}", nchw(n.conv3x3_wgrad_f32(x, dy)), ref)
+    for pm in (0, 1):
+        check(f"wgrad pm{pm}", nchw(n.conv3x3_wgrad_f32(x, dy, pm=pm)), ref)
     if batch == 64:
         for splits in (1, 3):
-            check(f"wgrad splits {splits}", nchw(n.conv3x3_wgrad_f32(x, dy, splits=splits)), ref)
+            for pm in (0, 1):
+                got = n.conv3x3_wgrad_f32(x, dy, splits=splits, pm=pm)
+                check(f"wgrad splits {splits} pm{pm}", nchw(got), ref)
 
 
 @pytest.mark.parametrize("batch", [1, 2, 64, 256])

@@ -102,9 +102,9 @@ def test_ddp_bf16_wire_two_ranks(tmp_path):
     assert _rel(b16[0], f32[0]) < 2e-2
     # the running statistics travel as fp32 next to the bf16 gradients
     for k in f32[0]:
-        if "running" in k:
-            d = (b16[0][k].double() - f32[0][k].double()).norm() / f32[0][k].double().norm()
-            assert float(d) < 2e-2, k
+        if "running" in k:      # means sit near zero: absolute, against the tensor's scale
+            scale = max(1.0, float(f32[0][k].abs().max()))
+            assert float((b16[0][k].double() - f32[0][k].double()).abs().max()) < 3e-2 * scale, k
 
 
 def test_mismatched_replicas_fail_loudly(tmp_path):
