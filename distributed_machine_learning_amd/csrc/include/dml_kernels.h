@@ -315,8 +315,9 @@ void conv1_fprop_f32(const float* x, const float* w, const float* bias, float* y
 void conv1_wgrad_f32(const float* x, const float* dy, float* dw, float* db, int batch, float* ws,
                      hipStream_t stream);
 size_t conv1_wgrad_f32_workspace_elems(int batch);
-// y = mask > 0 ? x : 0  (ReLU backward where no other kernel can fold it)
+// y = mask > 0 ? x : 0  (ReLU backward where no other kernel can fold it; n % 8 == 0)
 void relu_mask_f32(const float* x, const float* mask, float* y, size_t n, hipStream_t stream);
+void relu_mask(const bf16_raw* x, const bf16_raw* mask, bf16_raw* y, size_t n, hipStream_t stream);
 
 // ---- streams on hardware queues of their own (stream_probe.hip)
 // true if a kernel on `candidate` starts while a kernel on `busy` is still running

@@ -516,18 +516,6 @@ __global__ __launch_bounds__(256) void repack_dgrad_f32_kernel(const float* __re
     wd[idx] = wf[((size_t)co * 9 + (8 - t)) * cin + ci];
 }
 
-__global__ __launch_bounds__(256) void relu_mask_f32_kernel(const float4* __restrict__ x,
-                                                            const float4* __restrict__ mask,
-                                                            float4* __restrict__ y, size_t n4) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n4; i += stride) {
-        const float4 v = x[i], m = mask[i];
-        y[i] = float4{m.x > 0.f ? v.x : 0.f, m.y > 0.f ? v.y : 0.f, m.z > 0.f ? v.z : 0.f,
-                      m.w > 0.f ? v.w : 0.f};
-    }
-}
-
 void check_shape(const ConvShape& s, const char* who) {
     if (s.batch <= 0 || s.hw < 1 || s.hw > 32 || s.cin % 64 || s.cout % 64 || s.cin < 64 ||
         s.cout < 64)
@@ -692,15 +680,6 @@ void conv1_wgrad_f32(const float* x, const float* dy, float* dw, float* db, int 
                        batch * 1024);
     hipLaunchKernelGGL(conv1_wgrad_f32_fold_kernel, dim3(128), dim3(256), 0, stream,
                        (const float*)ws, dw, db, nb);
-}
-
-void relu_mask_f32(const float* x, const float* mask, float* y, size_t n, hipStream_t stream) {
-    if (n % 4) throw std::invalid_argument("relu_mask_f32: n must be a multiple of 4");
-    if (n == 0) return;
-    size_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(relu_mask_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       (const float4*)x, (const float4*)mask, (float4*)y, n / 4);
 }
 
 }  // namespace dml

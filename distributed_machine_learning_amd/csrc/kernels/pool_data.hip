@@ -120,6 +120,45 @@ void maxpool2x2_bwd(const float* x, const float* dy, float* dx, int batch, int h
     maxpool_bwd_launch(x, dy, dx, batch, hw, c, relu_mask, stream);
 }
 
+// ------------------------------------------------------------------------ ReLU backward
+// y = mask > 0 ? x : 0 with `mask` the ReLU's output: nn.ReLU backward
+// (/root/reference/part1/model.py:25) where no neighbouring kernel folds it (the engines fold it
+// into the backward-data epilogue or the pool's routing).
+template <typename T>
+__global__ __launch_bounds__(256) void relu_mask_kernel(const T* __restrict__ x,
+                                                        const T* __restrict__ mask,
+                                                        T* __restrict__ y, size_t n8) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n8; i += stride) {
+        float v[8], m[8];
+        load8(x + i * 8, v);
+        load8(mask + i * 8, m);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = m[k] > 0.f ? v[k] : 0.f;
+        store8(y + i * 8, v);
+    }
+}
+
+namespace {
+template <typename T>
+void relu_mask_launch(const T* x, const T* mask, T* y, size_t n, hipStream_t stream) {
+    if (n % 8) throw std::invalid_argument("relu_mask: n must be a multiple of 8");
+    if (n == 0) return;
+    size_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(relu_mask_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, x, mask, y,
+                       n / 8);
+}
+}  // namespace
+
+void relu_mask(const bf16_raw* x, const bf16_raw* mask, bf16_raw* y, size_t n, hipStream_t stream) {
+    relu_mask_launch(x, mask, y, n, stream);
+}
+void relu_mask_f32(const float* x, const float* mask, float* y, size_t n, hipStream_t stream) {
+    relu_mask_launch(x, mask, y, n, stream);
+}
+
 // ----------------------------------------------------------------------- column sum
 // out[c] += sum over rows (bias gradients): partial rows per block, then a small fold
 // kernel (dml_column_reduce.h); no atomics on `out`.

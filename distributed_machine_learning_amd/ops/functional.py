@@ -44,7 +44,7 @@ class _Conv3x3(torch.autograd.Function):
         x, wf, y = ctx.saved_tensors
         dy = dy.contiguous()
         if ctx.relu:
-            dy = torch.where(y > 0, dy, torch.zeros_like(dy))
+            dy = native.relu_mask(dy, y)
         if ctx.first:
             dw, db = native.conv1_wgrad(x, dy)
             return None, dw.permute(0, 3, 1, 2), db, None
@@ -52,6 +52,8 @@ class _Conv3x3(torch.autograd.Function):
         db = native.column_sum(dy)
         dx = None
         if ctx.needs_input_grad[0]:
+            # (the backward-data layout is derived here, once per step and only when an input
+            # gradient is wanted; the engines keep it resident and refresh it after the update)
             dx = native.conv3x3_dgrad(dy, native.repack_dgrad(wf))
         return dx, dw.permute(0, 3, 1, 2), db, None
 

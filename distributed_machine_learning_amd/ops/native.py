@@ -253,6 +253,20 @@ def _reduce_ws(device) -> torch.Tensor:
     return _REDUCE_WS[key]
 
 
+def relu_mask(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """``mask > 0 ? x : 0`` (ReLU backward from the ReLU's output), bf16 or fp32."""
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("relu_mask: bf16 or fp32")
+    _req(x, x.dtype, "x")
+    _req(mask, x.dtype, "mask")
+    if mask.shape != x.shape or x.numel() % 8:
+        raise ValueError("relu_mask: shapes must match, numel % 8 == 0")
+    y = torch.empty_like(x)
+    fn = lib().relu_mask if x.dtype == torch.bfloat16 else lib().relu_mask_f32
+    fn(x.data_ptr(), mask.data_ptr(), y.data_ptr(), x.numel(), _stream())
+    return y
+
+
 # --------------------------------------------------------------------------- pool
 def maxpool2x2_fwd(x: torch.Tensor) -> torch.Tensor:
     _req(x, torch.bfloat16, "x", 4)
