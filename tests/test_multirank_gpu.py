@@ -25,12 +25,13 @@ WORKER = os.path.join(HERE, "_sync_worker.py")
 NATIVE = ["--device", "cuda", "--backend", "native", "--dtype", "bf16", "--transport", "loopback"]
 
 
-def _run(tmp_path, tag, nproc, extra):
+def _run(tmp_path, tag, nproc, extra, dtype="bf16"):
     out = str(tmp_path / tag)
+    base = [a if a != "bf16" else dtype for a in NATIVE]
     if nproc == 1:
-        rc = subprocess.call([sys.executable, WORKER, "--out", out] + NATIVE + extra, timeout=300)
+        rc = subprocess.call([sys.executable, WORKER, "--out", out] + base + extra, timeout=300)
     else:
-        rc = launch(WORKER, ["--out", out] + NATIVE + extra, nproc, timeout_s=300)
+        rc = launch(WORKER, ["--out", out] + base + extra, nproc, timeout_s=300)
     assert rc == 0, tag
     return [torch.load(f"{out}.rank{r}", weights_only=True) for r in range(nproc)]
 
@@ -64,6 +65,19 @@ def test_two_ranks_mean_match_single_process_global_batch(tmp_path, sync):
     # per-sample gradients are scaled by an exact power of two (1/8 vs 1/16), so bf16 roundings
     # agree and only the fp32 summation order differs
     assert _rel(ranks[0], single) < 1e-4
+
+
+@pytest.mark.parametrize("sync", ["gather_scatter", "ddp"])
+def test_fp32_engine_two_ranks_match_single_process(tmp_path, sync):
+    """The fp32 engine (the reference's precision) under the same protocol."""
+    extra = ["--batch-norm"] if sync == "ddp" else []
+    single = _run(tmp_path, "single", 1, ["--sync", "none", "--batch-size", "16", "--iters", "3"]
+                  + ([] if sync == "ddp" else []), dtype="fp32")[0]
+    ranks = _run(tmp_path, sync, 2, ["--sync", sync, "--grad-reduce", "mean", "--batch-size", "8",
+                                     "--iters", "3", "--bucket-cap-mb", "4"] + extra, dtype="fp32")
+    assert _same(ranks[0], ranks[1])
+    if sync != "ddp":       # with BatchNorm the two half-batches normalise separately
+        assert _rel(ranks[0], single) < 1e-4
 
 
 def test_manual_modes_default_to_sum(tmp_path):
