@@ -207,8 +207,7 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         if (i == 0) continue;
         // (room for either block target, see wgrad_split_target())
         const ConvShape ws_shape = {max_batch_, c.hw, c.cin, c.cout};
-        const int s_a = conv3x3_wgrad_splits(ws_shape, 0), s_b = conv3x3_wgrad_splits(ws_shape, 288);
-        const int splits = s_a > s_b ? s_a : s_b;
+        const int splits = conv3x3_wgrad_max_splits(ws_shape);
         if (splits > 1) w = align_up(w + (size_t)splits * c.cout * 9 * c.cin);
     }
     ws_elems_ = w;

@@ -117,6 +117,30 @@ void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s
                    hipStream_t stream, int force_splits = 0 /* tuning */, float* slab = nullptr,
                    int split_target = 0 /* blocks to aim for, 0: the kernel's own optimum */);
 int conv3x3_wgrad_splits(ConvShape s, int split_target = 0);
+// the largest split count any kernel choice / block target can ask for at any batch size up to
+// s.batch (slab sizing)
+int conv3x3_wgrad_max_splits(ConvShape s);
+// Kernel choice behind conv3x3_wgrad: 0 / 1 = one tap per block (default: the better neighbour
+// of a concurrent backward-data chain), 2 = tap-resident (conv3x3_wgrad9) wherever it applies.
+// A tuning / test switch; set it before engines are built.
+void set_wgrad_variant(int variant);
+// Tuning: blocks every conv3x3_wgrad launch aims for, overriding the caller's split_target
+// (0 = no override).  Like the variant, set it before engines are built (slab sizing).
+void set_wgrad_block_target(int blocks);
+// Tuning: co tile (0 = 128 where it divides cout) and LDS ring depth of the tap-resident kernel
+// when conv3x3_wgrad dispatches to it.
+void set_wgrad9_config(int bco, int stages);
+int wgrad_variant();
+
+// The tap-resident kernel on its own: one block holds a dy tile (64 pixels x bco channels) and a
+// zero-bordered x tile in LDS and produces all nine taps of a bco x 64 tile.  `splits` comes from
+// conv3x3_wgrad9_splits (pixel-range splits, one slab of cout*9*cin floats each when > 1).
+bool conv3x3_wgrad9_supported(ConvShape s);
+int conv3x3_wgrad9_bco(ConvShape s, int force_bco = 0);
+int conv3x3_wgrad9_splits(ConvShape s, int bco, int force_splits = 0, int block_target = 0);
+int conv3x3_wgrad9_splits_bound(ConvShape s, int bco, int block_target = 0);
+void conv3x3_wgrad9(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
+                    hipStream_t stream, float* slab, int bco, int splits, int stages = 3);
 
 // dst[job][i] = sum_k src[job][k * count + i] for up to 32 jobs in one launch (offsets in
 // floats from the two bases, counts multiples of 4): the reduction behind the slab mode above.

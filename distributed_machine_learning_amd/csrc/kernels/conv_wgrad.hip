@@ -1,4 +1,5 @@
-// conv3x3 backward-weight as an MFMA implicit GEMM, plus the weight repack for dgrad.
+// conv3x3 backward-weight as an MFMA implicit GEMM (one tap per block), the dispatcher between
+// it and the tap-resident kernel (conv_wgrad9.hip), and the weight repack for dgrad.
 //
 // Reference op: the weight / bias gradient autograd computes for nn.Conv2d
 // (/root/reference/part1/model.py:18-23) inside loss.backward()
@@ -13,18 +14,20 @@
 // read: per 16 lanes it takes a 4 (pixels) x 16 (channels) block and hands each lane the
 // four pixels of one channel, so two reads give the 8 consecutive-K values a lane needs.
 //
-// CDNA4 mapping
+// CDNA4 mapping of the per-tap kernel
 //   * block = 256 threads (4 wave64, 2x2), tile BCO x BCI channels of ONE tap, K step
 //     64 pixels = 4 x v_mfma_f32_32x32x16_bf16 per 32x32 tile.
 //   * 32x32 accumulators put 32 consecutive ci on lanes 0..31 of one register, so the
-//     fp32 result leaves as 128-byte row segments - the shape at which global fp32
-//     atomics run at full rate when the pixel range is split across blocks.
+//     fp32 result leaves as 128-byte row segments.
 //   * LDS rows are padded by 64 bytes (row stride = 2*channels + 64): the four pixel rows
 //     and two 16-channel groups touched by one half-wave of a transposing read then hit
 //     disjoint banks.
-//   * Two LDS stages, register staging, one barrier per K step (same pipeline as fprop).
-//   * The pixel range is split over blockIdx.y until the grid covers the chip; partial
-//     sums are combined with fp32 atomics into the (pre-zeroed) flat gradient buffer.
+//   * Two LDS stages filled through registers (buffer loads, out-of-range offsets for the
+//     padding), one barrier per K step.
+//   * The pixel range is split over blockIdx.y until the grid covers the chip.  With a slab
+//     every split stores its partial tile with plain stores and sum_slabs_batch adds them in a
+//     fixed order (what the engines use: deterministic); without one the splits accumulate
+//     into the pre-zeroed gradient with fp32 atomics.
 #include <stdexcept>
 #include <string>
 
@@ -222,8 +225,9 @@ int ilog2w(int v) {
 // overrides the block target: when the kernel runs on a side stream next to a longer main
 // chain, fewer splits (less slab traffic competing with the main chain) serve the step better.
 struct SplitPlan { int splits, steps_per_split; };
-SplitPlan plan_splits(int M, int tiles, int force_splits, bool slab_mode = true,
-                      int split_target = 0) {
+// the split count before it is rounded to whole steps per split: an upper bound for every
+// batch size up to the one M stands for
+int plan_splits_bound(int M, int tiles, bool slab_mode, int split_target) {
     const int total_steps = (M + 63) / 64;
     const int target = split_target > 0 ? split_target : slab_mode ? 432 : 288;
     int splits = slab_mode ? (target + tiles / 2) / tiles : (target + tiles - 1) / tiles;
@@ -232,6 +236,12 @@ SplitPlan plan_splits(int M, int tiles, int force_splits, bool slab_mode = true,
     if (slab_mode && tiles >= 128 && total_steps <= 16) splits = 1;
     const int max_splits = total_steps >= 4 ? total_steps / 4 : 1;
     if (splits > max_splits) splits = max_splits;
+    return splits < 1 ? 1 : splits;
+}
+SplitPlan plan_splits(int M, int tiles, int force_splits, bool slab_mode = true,
+                      int split_target = 0) {
+    const int total_steps = (M + 63) / 64;
+    int splits = plan_splits_bound(M, tiles, slab_mode, split_target);
     if (force_splits > 0) splits = force_splits < total_steps ? force_splits : total_steps;
     if (splits < 1) splits = 1;
     const int sps = (total_steps + splits - 1) / splits;
@@ -271,12 +281,77 @@ void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab
 
 }  // namespace
 
+namespace {
+int g_variant = 0;
+int g_target = 0;       // block target override (tuning), 0: the caller's
+int g_bco = 0, g_stages = 2;    // tap-resident kernel: co tile (0: 128 where it divides), ring depth
+
+// Which kernel serves a call of conv3x3_wgrad.  The engines run weight gradients on a side
+// stream NEXT TO the backward-data chain, and there the per-tap kernel is the better neighbour:
+// measured inside the VGG-11+BN step at batch 256 it gives 0.657 ms/step against 0.667-0.68 with
+// the tap-resident kernel (any co tile, ring depth or block target), although that kernel is
+// 18 % faster when it has the GPU to itself (121 against 148 us over the seven layers) - sharing
+// CUs it keeps one wave per SIMD and loses more than the per-tap kernel's many small blocks.
+// So the default is the per-tap kernel and the tap-resident one is opt-in (variant 2) or called
+// directly (conv3x3_wgrad9, which the stand-alone op uses).
+bool use_tap_resident(const ConvShape& s) {
+    return g_variant == 2 && conv3x3_wgrad9_supported(s);
+}
+}  // namespace
+
+void set_wgrad_variant(int variant) {
+    if (variant < 0 || variant > 2) throw std::invalid_argument("set_wgrad_variant: 0, 1 or 2");
+    g_variant = variant;
+}
+int wgrad_variant() { return g_variant; }
+void set_wgrad9_config(int bco, int stages) {
+    if ((bco != 0 && bco != 64 && bco != 128) || (stages != 2 && stages != 3))
+        throw std::invalid_argument("set_wgrad9_config: bco in {0, 64, 128}, stages in {2, 3}");
+    g_bco = bco;
+    g_stages = stages;
+}
+void set_wgrad_block_target(int blocks) {
+    if (blocks < 0) throw std::invalid_argument("set_wgrad_block_target: negative");
+    g_target = blocks;
+}
+
 int conv3x3_wgrad_splits(ConvShape s, int split_target) {
+    if (g_target > 0) split_target = g_target;
+    if (use_tap_resident(s))
+        return conv3x3_wgrad9_splits(s, conv3x3_wgrad9_bco(s, g_bco), 0, split_target);
     return plan_splits(s.batch * s.hw * s.hw, wgrad_tiles(s), 0, true, split_target).splits;
+}
+
+int conv3x3_wgrad_max_splits(ConvShape s) {
+    int m = 1;
+    const int M = s.batch * s.hw * s.hw;
+    const int steps = (M + 63) / 64, cap = steps >= 4 ? steps / 4 : 1;
+    const int tiles = wgrad_tiles(s);
+    for (int target : {0, 288, g_target}) {
+        // per-tap plan without its short-reduction rule (which depends on the batch size)
+        int a = ((target > 0 ? target : 432) + tiles / 2) / tiles;
+        a = a > cap ? cap : a;
+        m = a > m ? a : m;
+        if (conv3x3_wgrad9_supported(s)) {
+            for (int bco : {64, 128}) {
+                if (s.cout % bco) continue;
+                const int b = conv3x3_wgrad9_splits_bound(s, bco, target);
+                m = b > m ? b : m;
+            }
+        }
+    }
+    return m;
 }
 
 void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s,
                    hipStream_t stream, int force_splits, float* slab, int split_target) {
+    if (g_target > 0) split_target = g_target;
+    if (slab && force_splits == 0 && use_tap_resident(s)) {
+        const int bco = conv3x3_wgrad9_bco(s, g_bco);
+        conv3x3_wgrad9(x, dy, dw, s, stream, slab, bco,
+                       conv3x3_wgrad9_splits(s, bco, 0, split_target), g_stages);
+        return;
+    }
     if (s.batch <= 0 || s.hw < 1 || s.hw > 32 || (s.hw & (s.hw - 1)) || s.cin % 64 ||
         s.cout % 64 || s.cin < 64 || s.cout < 64)
         throw std::invalid_argument("conv3x3_wgrad: needs hw power of two <= 32, cin % 64 == 0, "

@@ -12,6 +12,7 @@ compared against the stock-torch model; their internal layout (conv weights
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -47,6 +48,14 @@ class NativeBackend:
         C = native.lib()
         widths = [-1 if w == "M" else int(w) for w in VGG_WIDTHS[cfg.arch]]
         engine_cls = C.VggEngineF32 if self.fp32 else C.VggEngine
+        # kernel tuning switches (they size the engine's slabs, so they come first)
+        if os.environ.get("DML_WGRAD_VARIANT"):
+            C.set_wgrad_variant(int(os.environ["DML_WGRAD_VARIANT"]))
+        if os.environ.get("DML_WGRAD9"):        # "<co tile>,<ring stages>"
+            bco, stages = os.environ["DML_WGRAD9"].split(",")
+            C.set_wgrad9_config(int(bco), int(stages))
+        if os.environ.get("DML_WGRAD_TARGET"):
+            C.set_wgrad_block_target(int(os.environ["DML_WGRAD_TARGET"]))
         self.engine = engine_cls(widths, cfg.batch_size, cfg.batch_norm, cfg.num_classes)
         e = self.engine
         f32 = dict(dtype=torch.float32, device=device)

@@ -136,7 +136,27 @@ def conv3x3_dgrad(dy: torch.Tensor, wd: torch.Tensor, relu_mask: Optional[torch.
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
-    """``dw[co][tap][ci] = sum_p dy[p][co] x[p (+) tap][ci]`` as fp32 ``[Cout,3,3,Cin]``."""
+    """``dw[co][tap][ci] = sum_p dy[p][co] x[p (+) tap][ci]`` as fp32 ``[Cout,3,3,Cin]``.
+
+    A stand-alone call has the GPU to itself, where the tap-resident kernel is the faster one
+    (and, summing per-split slabs, deterministic); shapes it does not cover take the per-tap
+    kernel with atomic accumulation."""
+    _req(x, torch.bfloat16, "x", 4)
+    _req(dy, torch.bfloat16, "dy", 4)
+    b, h, w, cin = x.shape
+    cout = dy.shape[3]
+    if tuple(dy.shape[:3]) != (b, h, w) or h != w:
+        raise ValueError("conv3x3_wgrad: shape mismatch")
+    if h in (2, 4, 8, 16, 32) and cin % 64 == 0 and cout % 64 == 0:
+        return conv3x3_wgrad9(x, dy)
+    dw = torch.zeros(cout, 3, 3, cin, dtype=torch.float32, device=x.device)
+    lib().conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), b, h, cin, cout, _stream())
+    return dw
+
+
+def conv3x3_wgrad_per_tap(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """The one-tap-per-block kernel with atomic accumulation (what ``conv3x3_wgrad`` falls back
+    to; the engines use it in its slab mode)."""
     _req(x, torch.bfloat16, "x", 4)
     _req(dy, torch.bfloat16, "dy", 4)
     b, h, w, cin = x.shape
@@ -146,6 +166,25 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     dw = torch.zeros(cout, 3, 3, cin, dtype=torch.float32, device=x.device)
     lib().conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), b, h, cin, cout, _stream())
     return dw
+
+
+def conv3x3_wgrad9(x: torch.Tensor, dy: torch.Tensor, bco: int = 0, splits: int = 0,
+                   stages: int = 3, target: int = 0) -> torch.Tensor:
+    """The tap-resident weight-gradient kernel on its own (``conv3x3_wgrad`` picks between it and
+    the one-tap-per-block kernel).  ``splits`` = 0 takes the kernel's plan for ``target`` blocks;
+    the split slabs are summed here with a tensor op (the engine uses ``sum_slabs_batch``)."""
+    _req(x, torch.bfloat16, "x", 4)
+    _req(dy, torch.bfloat16, "dy", 4)
+    b, h, w, cin = x.shape
+    cout = dy.shape[3]
+    if tuple(dy.shape[:3]) != (b, h, w) or h != w:
+        raise ValueError("conv3x3_wgrad9: shape mismatch")
+    n = lib().conv3x3_wgrad9_splits(b, h, cin, cout, bco, splits, target)
+    dw = torch.empty(cout, 3, 3, cin, dtype=torch.float32, device=x.device)
+    slab = torch.empty(n, cout, 3, 3, cin, dtype=torch.float32, device=x.device) if n > 1 else None
+    lib().conv3x3_wgrad9(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), b, h, cin, cout, _stream(),
+                         _ptr(slab), bco, n, stages)
+    return slab.sum(0) if n > 1 else dw
 
 
 def pack_conv1_weights(w: torch.Tensor) -> torch.Tensor:

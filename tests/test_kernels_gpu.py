@@ -203,10 +203,11 @@ def test_conv3x3_wgrad(batch, cin, cout, hw):
     n = native()
     x = rand_bf16(batch, hw, hw, cin, seed=8)
     dy = rand_bf16(batch, hw, hw, cout, seed=9)
-    dw = n.conv3x3_wgrad(x, dy)
     ref = torch.nn.grad.conv2d_weight(nchw(x), (cout, cin, 3, 3), nchw(dy), padding=1)
-    check(f"wgrad {cin}->{cout}@{hw} B{batch}", dw.permute(0, 3, 1, 2), ref, rtol=2e-3,
-          atol_scale=2e-3)
+    for fn in (n.conv3x3_wgrad, n.conv3x3_wgrad_per_tap):
+        dw = fn(x, dy)
+        check(f"wgrad {cin}->{cout}@{hw} B{batch}", dw.permute(0, 3, 1, 2), ref, rtol=2e-3,
+              atol_scale=2e-3)
 
 
 @pytest.mark.parametrize("cin,cout,hw,batch", [(64, 128, 16, 64), (256, 256, 8, 256), (512, 512, 4, 256)])
@@ -235,15 +236,37 @@ def test_conv3x3_wgrad_slab_mode_is_deterministic(cin, cout, hw, batch):
     check("wgrad slab", outs[0].permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=2e-3)
 
 
+@pytest.mark.parametrize("hw,cin,cout,batch", [
+    (2, 512, 512, 256), (2, 128, 64, 5), (4, 256, 512, 256), (4, 64, 128, 3), (8, 128, 256, 256),
+    (8, 256, 256, 7), (16, 64, 128, 64), (16, 128, 64, 2), (32, 64, 64, 16), (32, 64, 128, 3)])
+@pytest.mark.parametrize("bco,stages", [(64, 3), (128, 3), (64, 2), (128, 2)])
+def test_conv3x3_wgrad_tap_resident(hw, cin, cout, batch, bco, stages):
+    """All nine taps from one dy tile and one zero-bordered x tile: every geometry (position-major
+    2x2, whole images, image-row bands with halo rows), both co tiles, both ring depths, the
+    kernel's own split plan and a single block per tile, against fp32 autograd."""
+    n = native()
+    if cout % bco:
+        pytest.skip("co tile does not divide cout")
+    x = rand_bf16(batch, hw, hw, cin, seed=81)
+    dy = rand_bf16(batch, hw, hw, cout, seed=82)
+    ref = torch.nn.grad.conv2d_weight(nchw(x), (cout, cin, 3, 3), nchw(dy), padding=1)
+    steps = (batch * hw * hw + 63) // 64
+    for splits in sorted({0, 1, min(3, steps)}):
+        dw = n.conv3x3_wgrad9(x, dy, bco=bco, splits=splits, stages=stages)
+        check(f"wgrad9 {cin}->{cout}@{hw} B{batch} bco{bco} st{stages} sp{splits}",
+              dw.permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=2e-3)
+
+
 def test_conv3x3_wgrad_b256():
     n = native()
     for cin, cout, hw in [(64, 128, 16), (512, 512, 2)]:
         x = rand_bf16(256, hw, hw, cin, seed=10)
         dy = rand_bf16(256, hw, hw, cout, seed=11)
-        dw = n.conv3x3_wgrad(x, dy)
         ref = torch.nn.grad.conv2d_weight(nchw(x), (cout, cin, 3, 3), nchw(dy), padding=1)
-        check(f"wgrad {cin}->{cout}@{hw} B256", dw.permute(0, 3, 1, 2), ref, rtol=2e-3,
-              atol_scale=2e-3)
+        for fn in (n.conv3x3_wgrad, n.conv3x3_wgrad_per_tap):
+            dw = fn(x, dy)
+            check(f"wgrad {cin}->{cout}@{hw} B256", dw.permute(0, 3, 1, 2), ref, rtol=2e-3,
+                  atol_scale=2e-3)
 
 
 @pytest.mark.parametrize("batch", [2, 64, 256])

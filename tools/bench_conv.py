@@ -51,7 +51,9 @@ def main():
         waves_opts = (4, 8, 9, 16)
         for kind in which:
             if kind == "wgrad":
-                slab = torch.empty(64 * cout * 9 * cin, device=DEV)
+                C.set_wgrad_variant(1)      # the one-tap-per-block kernel
+                slab = torch.empty(max(64, C.conv3x3_wgrad_max_splits(B, hw, cin, cout)) *
+                                   cout * 9 * cin, device=DEV)
                 for sp in (0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64):
                     if sp > (M + 63) // 64:
                         continue
@@ -61,6 +63,22 @@ def main():
                           f"{flops / t / 1e6:7.1f} TF/s (slab mode, sum kernel not included)",
                           flush=True)
                 del slab
+                C.set_wgrad_variant(0)
+                # tap-resident kernel: co tile x ring depth x block target (slab sum not included)
+                for bco in (64, 128):
+                    if cout % bco:
+                        continue
+                    for stages in (2, 3):
+                        for target in (64, 128, 256, 512):
+                            n = C.conv3x3_wgrad9_splits(B, hw, cin, cout, bco, 0, target)
+                            slab = torch.empty(max(n, 1) * cout * 9 * cin, device=DEV)
+                            t = timeit(lambda: C.conv3x3_wgrad9(x.data_ptr(), dy.data_ptr(),
+                                                                dw.data_ptr(), B, hw, cin, cout, s,
+                                                                slab.data_ptr(), bco, n, stages))
+                            print(f"wgrad9 {cin:4d}->{cout:4d}@{hw:2d} bco={bco:3d} stages={stages} "
+                                  f"target={target:3d} splits={n:3d} {t:8.1f} us "
+                                  f"{flops / t / 1e6:7.1f} TF/s", flush=True)
+                            del slab
                 continue
             for (bm, bn, sp), pm, nw in itertools.product(plans, (0, 1), waves_opts):
                 if nw in (8, 9) and (bm, bn) != (128, 128):

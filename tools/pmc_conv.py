@@ -25,7 +25,10 @@ def main():
             bias = torch.zeros(cout, device="cuda")
             native.conv3x3_fwd(x, w, bias, relu=True)
             native.conv3x3_dgrad(dy, native.repack_dgrad(w))
-            native.conv3x3_wgrad(x, dy)
+            native.conv3x3_wgrad_per_tap(x, dy)       # one tap per block
+            native.conv3x3_wgrad9(x, dy, bco=64, stages=2)        # tap-resident, both co tiles
+            if cout % 128 == 0:
+                native.conv3x3_wgrad9(x, dy, bco=128, stages=3)
     x4 = native.fill_uniform_(torch.empty(B, 32, 32, 4, dtype=torch.bfloat16, device="cuda"), 4)
     w1 = native.pack_conv1_weights(torch.randn(64, 3, 3, 3, device="cuda"))
     native.conv1_fwd(x4, w1, torch.zeros(64, device="cuda"))
