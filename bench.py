@@ -87,6 +87,9 @@ def parse(argv=None):
     ap.add_argument("--wgrad-overlap", type=int, default=1, choices=(0, 1),
                     help="weight-gradient kernels on a second HIP stream")
     ap.add_argument("--wgrad-group", type=int, default=0, help="0 = auto")
+    ap.add_argument("--update-overlap", type=int, default=None,
+                    help="first conv layer updated on the side stream next to the next forward "
+                         "(0 off, -1 auto)")
     ap.add_argument("--fused-optimizer", type=int, default=0, choices=(0, 1),
                     help="SGD slices inside backward, behind each group's / bucket's gradients")
     ap.add_argument("--distinct-batches", type=int, default=4)
@@ -233,6 +236,8 @@ def run_rank(ns) -> None:
                       serialize_streams=ns.serialize_streams, comm_timeout_s=ns.comm_timeout,
                       wgrad_overlap=bool(ns.wgrad_overlap), wgrad_group=ns.wgrad_group,
                       fused_optimizer=bool(ns.fused_optimizer),
+                      update_overlap=(TrainConfig().update_overlap if ns.update_overlap is None
+                                      else int(ns.update_overlap)),
                       summary=False, eval=False)
     torch.manual_seed(SEED)
     backend = make_backend(cfg, device, comm)

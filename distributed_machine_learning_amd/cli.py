@@ -62,6 +62,10 @@ def build_parser(defaults: TrainConfig, distributed_flags: bool = True) -> argpa
                     help="run backward's weight-gradient kernels on a second HIP stream")
     wo.add_argument("--no-wgrad-overlap", dest="wgrad_overlap", action="store_false")
     p.add_argument("--wgrad-group", type=int, default=defaults.wgrad_group)
+    p.add_argument("--update-overlap", dest="update_overlap", type=int,
+                   default=defaults.update_overlap,
+                   help="first conv layer whose SGD update (with all later layers) runs on the side "
+                        "stream next to the next forward's first layers (0 off, -1 auto)")
     p.add_argument("--fused-optimizer", dest="fused_optimizer", action="store_true",
                    default=defaults.fused_optimizer,
                    help="optimizer update in slices inside backward (behind each group's sums / "

@@ -66,6 +66,9 @@ class TrainConfig:
     use_graph: bool = False                # capture the native train step in a hipGraph
     wgrad_overlap: bool = True             # weight-gradient kernels on a second HIP stream
     fused_optimizer: bool = False          # SGD slices inside backward (needs wgrad_overlap)
+    # first conv layer whose update (with everything after it) runs on the side stream next to
+    # the following forward's first layers; 0 = off, -1 = from the first 4x4 layer on
+    update_overlap: int = 0
     wgrad_group: int = 0                   # layers per hand-off to that stream; 0 = auto
 
     # --- data ---

@@ -219,6 +219,8 @@ VggEngine::~VggEngine() {
     if (graph_) (void)hipGraphDestroy(graph_);
     for (hipEvent_t e : hand_off_) (void)hipEventDestroy(e);
     if (side_done_) (void)hipEventDestroy(side_done_);
+    if (grads_final_) (void)hipEventDestroy(grads_final_);
+    if (late_done_) (void)hipEventDestroy(late_done_);
     if (wgrad_stream_) (void)hipStreamDestroy(wgrad_stream_);
 }
 
@@ -234,6 +236,8 @@ void VggEngine::set_wgrad_overlap(bool on, int group, hipStream_t compute_stream
         for (hipEvent_t& e : hand_off_)
             check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
         check_hip(hipEventCreateWithFlags(&side_done_, hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&grads_final_, hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&late_done_, hipEventDisableTiming), "hipEventCreate");
     }
     if ((on != wgrad_overlap_ || group != wgrad_group_) && graph_exec_) {
         (void)hipGraphExecDestroy(graph_exec_);     // a captured step has the old schedule
@@ -241,6 +245,19 @@ void VggEngine::set_wgrad_overlap(bool on, int group, hipStream_t compute_stream
     }
     wgrad_overlap_ = on;
     wgrad_group_ = group;
+}
+
+void VggEngine::set_update_overlap(int first_late_layer) {
+    if (first_late_layer < 0 || first_late_layer > (int)convs_.size())
+        throw std::invalid_argument("VggEngine: update overlap layer outside the network");
+    if (late_pending_) throw std::logic_error("VggEngine: join_update() before changing the overlap");
+    late_layer_ = first_late_layer;
+}
+
+void VggEngine::join_update(hipStream_t stream) {
+    if (!late_pending_) return;
+    check_hip(hipStreamWaitEvent(stream, late_done_, 0), "hipStreamWaitEvent(late update)");
+    late_pending_ = false;
 }
 
 void VggEngine::set_fused_optimizer(bool on, float lr, float momentum, float weight_decay,
@@ -352,6 +369,7 @@ void VggEngine::flush_wgrad_sums(hipStream_t stream) {
 
 void VggEngine::refresh_weights(hipStream_t stream) {
     if (!params_) throw std::logic_error("VggEngine: bind() first");
+    join_update(stream);
     // Full refresh: needed when the master weights were written from outside (initialisation,
     // load_state_dict); during training the optimizer kernel keeps the shadow current.
     cast_f32_to_bf16(params_, arena_ + shadow_off_, param_elems_, stream);
@@ -374,26 +392,34 @@ std::vector<std::vector<long long>> VggEngine::layer_table() const {
 
 void VggEngine::repack_all(hipStream_t stream, const float* copy_src, float* copy_dst,
                            size_t copy_n) {
-    // backward-data weight layout for every conv after the first, 16 layers per launch; the
-    // first layer's padded bf16 layout rides in the first launch
-    const float* c1 = params_ + convs_[0].w_off;
-    if (convs_.size() == 1) {
-        repack_conv1_weights(c1, arena_ + w1_off_, stream);
+    repack_layers(1, (int)convs_.size(), true, stream, copy_src, copy_dst, copy_n);
+}
+
+void VggEngine::repack_layers(int lo, int hi, bool conv1, hipStream_t stream, const float* copy_src,
+                              float* copy_dst, size_t copy_n) {
+    // backward-data weight layout for conv layers [lo, hi), 16 layers per launch; the first
+    // layer's padded bf16 layout and the copy ride in the first launch
+    const float* c1 = conv1 ? params_ + convs_[0].w_off : nullptr;
+    if (lo >= hi) {
+        if (c1) repack_conv1_weights(c1, arena_ + w1_off_, stream);
         if (copy_n)
             check_hip(hipMemcpyAsync(copy_dst, copy_src, copy_n * sizeof(float),
                                      hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(buffers)");
+        return;
     }
     RepackJobs jobs;
-    for (size_t i = 1; i < convs_.size(); ++i) {
+    bool first = true;
+    for (int i = lo; i < hi; ++i) {
         const Conv& c = convs_[i];
         jobs.cout[jobs.n] = c.cout;
         jobs.cin[jobs.n] = c.cin;
         jobs.src_off[jobs.n] = shadow_off_ + c.w_off;
         jobs.dst_off[jobs.n] = c.wd_off;
-        if (++jobs.n == RepackJobs::kMax || i + 1 == convs_.size()) {
-            repack_dgrad_weights_batch(arena_, arena_, jobs, stream, c1, arena_ + w1_off_, copy_src,
-                                       copy_dst, c1 ? copy_n : 0);
-            c1 = nullptr;
+        if (++jobs.n == RepackJobs::kMax || i + 1 == hi) {
+            repack_dgrad_weights_batch(arena_, arena_, jobs, stream, first ? c1 : nullptr,
+                                       arena_ + w1_off_, first ? copy_src : nullptr,
+                                       first ? copy_dst : nullptr, first ? copy_n : 0);
+            first = false;
             jobs.n = 0;
         }
     }
@@ -407,6 +433,8 @@ void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t
     float* slab = ws_ + slab_off_;
     for (size_t i = 0; i < convs_.size(); ++i) {
         const Conv& c = convs_[i];
+        // the deep layers' weights may still be on their way (see set_update_overlap)
+        if (late_pending_ && (int)i >= late_layer_) join_update(stream);
         uint16_t* dst = arena_ + (bn_ ? c.pre_off : c.out_off);
         // in training the conv epilogue also leaves the BatchNorm statistics partials
         BnPartials part;
@@ -457,6 +485,7 @@ void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t
             in = arena_ + c.pool_off;
         }
     }
+    join_update(stream);        // (a network whose late part is only the classifier)
     // in training the classifier runs fused with the loss and its backward (see backward())
     if (!training)
         linear_fwd(in, params_ + fcw_off_, params_ + fcb_off_, ws_ + logits_off_, batch, fc_in_,
@@ -665,19 +694,37 @@ void VggEngine::optimizer_step(float lr, float momentum, float weight_decay, flo
                                hipStream_t stream) {
     TraceRange range("optimizer");
     if (reducer_) reducer_->wait_all(stream);
+    // the running statistics every rank adopts from rank 0 (see BucketReducer) arrived with the
+    // gradients: their copy into the live buffers rides in the repack launch
+    const float* bsrc = nullptr; float* bdst = nullptr; size_t bn = 0;
+    if (reducer_) (void)reducer_->take_pending_buffers(&bsrc, &bdst, &bn);
+    const int nconv = (int)convs_.size();
     if (opt_applied_) {
         if (lr != opt_.lr || momentum != opt_.mu || weight_decay != opt_.wd || grad_scale != opt_.gscale)
             throw std::logic_error("VggEngine: optimizer_step() disagrees with the hyper-parameters "
                                    "the fused update already applied in backward");
         opt_applied_ = false;
+    } else if (late_layer_ > 0 && late_layer_ <= nconv && wgrad_overlap_ && wgrad_stream_ &&
+               !capturing_) {
+        // Early layers here, deep layers (and the classifier) on the side stream: the next forward
+        // needs the early ones first and reaches the deep ones tens of microseconds later.
+        join_update(stream);
+        const size_t cut = layer_begin(late_layer_);
+        check_hip(hipEventRecord(grads_final_, stream), "hipEventRecord(grads final)");
+        sgd_momentum(params_, grads_, mom_, arena_ + shadow_off_, cut, lr, momentum, weight_decay,
+                     grad_scale, false, stream);
+        repack_layers(1, late_layer_ < nconv ? late_layer_ : nconv, true, stream, bsrc, bdst, bn);
+        check_hip(hipStreamWaitEvent(wgrad_stream_, grads_final_, 0), "hipStreamWaitEvent(grads final)");
+        sgd_momentum(params_ + cut, grads_ + cut, mom_ + cut, arena_ + shadow_off_ + cut,
+                     param_elems_ - cut, lr, momentum, weight_decay, grad_scale, false, wgrad_stream_);
+        repack_layers(late_layer_ < 1 ? 1 : late_layer_, nconv, false, wgrad_stream_);
+        check_hip(hipEventRecord(late_done_, wgrad_stream_), "hipEventRecord(late update)");
+        late_pending_ = true;
+        return;
     } else {
         sgd_momentum(params_, grads_, mom_, arena_ + shadow_off_, param_elems_, lr, momentum,
                      weight_decay, grad_scale, false, stream);
     }
-    // the running statistics every rank adopts from rank 0 (see BucketReducer) arrived with the
-    // gradients: their copy into the live buffers rides in the repack launch
-    const float* bsrc = nullptr; float* bdst = nullptr; size_t bn = 0;
-    if (reducer_) (void)reducer_->take_pending_buffers(&bsrc, &bdst, &bn);
     repack_all(stream, bsrc, bdst, bn);
 }
 
@@ -708,7 +755,9 @@ void VggEngine::capture_train_step(const uint16_t* x, const int64_t* target, int
     if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
     if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
     const long long saved = bn_steps_;
+    join_update(stream);
     check_hip(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal), "BeginCapture");
+    capturing_ = true;      // (a captured step updates everything inside the graph)
     try {
         forward_backward(x, target, batch, stream);
         optimizer_step(lr, momentum, weight_decay, grad_scale, stream);
@@ -717,8 +766,10 @@ void VggEngine::capture_train_step(const uint16_t* x, const int64_t* target, int
         (void)hipStreamEndCapture(stream, &g);
         if (g) (void)hipGraphDestroy(g);
         bn_steps_ = saved;
+        capturing_ = false;
         throw;
     }
+    capturing_ = false;
     check_hip(hipStreamEndCapture(stream, &graph_), "EndCapture");
     check_hip(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0), "GraphInstantiate");
     bn_steps_ = saved;      // capturing enqueues nothing
@@ -726,6 +777,7 @@ void VggEngine::capture_train_step(const uint16_t* x, const int64_t* target, int
 
 void VggEngine::replay_train_step(hipStream_t stream) {
     if (!graph_exec_) throw std::logic_error("VggEngine: capture_train_step() first");
+    join_update(stream);
     check_hip(hipGraphLaunch(graph_exec_, stream), "GraphLaunch");
     if (bn_) ++bn_steps_;
 }
@@ -763,6 +815,9 @@ void bind_engine(py::module_& m) {
         .def("set_fused_optimizer", &VggEngine::set_fused_optimizer, py::arg("on"),
              py::arg("lr") = 0.f, py::arg("momentum") = 0.f, py::arg("weight_decay") = 0.f,
              py::arg("grad_scale") = 1.f)
+        .def("set_update_overlap", &VggEngine::set_update_overlap)
+        .def_property_readonly("update_overlap", &VggEngine::update_overlap)
+        .def("join_update", [](VggEngine& e, uintptr_t s) { e.join_update((hipStream_t)s); })
         .def_property_readonly("wgrad_overlap", &VggEngine::wgrad_overlap)
         .def_property_readonly("wgrad_stream", [](VggEngine& e) { return (uintptr_t)e.wgrad_stream(); })
         .def("set_reducer", [](VggEngine& e, BucketReducer* r,

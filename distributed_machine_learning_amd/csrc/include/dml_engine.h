@@ -86,6 +86,18 @@ class VggEngine {
                              float weight_decay = 0.f, float grad_scale = 1.f);
     bool wgrad_overlap() const { return wgrad_overlap_; }
     hipStream_t wgrad_stream() const { return wgrad_stream_; }
+    // Overlap the parameter update of the deep layers with the first layers of the NEXT forward
+    // (side-stream mode only).  optimizer_step() then updates and repacks the conv layers below
+    // `first_late_layer` on the caller's stream and everything from that layer on (most of the
+    // parameters: the wide layers and the classifier) on the side stream; the next forward - or
+    // any other reader, see join_update() - waits for the side stream right before it reaches
+    // that layer.  Same kernels on the same values: results are bit-identical.  0 = off.
+    void set_update_overlap(int first_late_layer);
+    int update_overlap() const { return late_layer_; }
+    // make `stream` wait for a deep-layer update still running on the side stream (a no-op when
+    // none is pending); every engine entry point that touches parameters does this itself, callers
+    // that read the bound parameter / momentum buffers directly call it first
+    void join_update(hipStream_t stream);
 
     // bf16 shadow + conv1 / dgrad repacks from the fp32 master weights
     void refresh_weights(hipStream_t stream);
@@ -155,6 +167,10 @@ class VggEngine {
     void sgd_slice(size_t begin, size_t end, hipStream_t stream);
     void repack_all(hipStream_t stream, const float* copy_src = nullptr, float* copy_dst = nullptr,
                     size_t copy_n = 0);
+    // dgrad layouts of conv layers [lo, hi) (lo >= 1); with `conv1` also the first layer's padded
+    // layout, and a small fp32 copy riding in the first launch
+    void repack_layers(int lo, int hi, bool conv1, hipStream_t stream, const float* copy_src = nullptr,
+                       float* copy_dst = nullptr, size_t copy_n = 0);
 
     std::vector<Conv> convs_;
     int max_batch_, num_classes_, fc_in_;
@@ -186,6 +202,10 @@ class VggEngine {
     bool side_busy_ = false;                // side-stream work the main stream has not waited for
     hipGraph_t graph_ = nullptr;
     hipGraphExec_t graph_exec_ = nullptr;
+    int late_layer_ = 0;                    // first layer updated on the side stream (0: none)
+    hipEvent_t grads_final_ = nullptr, late_done_ = nullptr;
+    bool late_pending_ = false;             // a side-stream update the main stream has not waited for
+    bool capturing_ = false;
 };
 
 // The same network with every tensor in fp32 (the reference's precision); see

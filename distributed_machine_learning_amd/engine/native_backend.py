@@ -59,13 +59,13 @@ class NativeBackend:
         self.engine = engine_cls(widths, cfg.batch_size, cfg.batch_norm, cfg.num_classes)
         e = self.engine
         f32 = dict(dtype=torch.float32, device=device)
-        self.params = torch.zeros(e.param_elems, **f32)
+        self._params = torch.zeros(e.param_elems, **f32)
         self.grads = torch.zeros(e.param_elems, **f32)
-        self.momentum = torch.zeros(e.param_elems, **f32)
+        self._momentum = torch.zeros(e.param_elems, **f32)
         self.bn_buffers = torch.zeros(max(e.bn_elems, 1), **f32)
         self.arena = torch.zeros(e.arena_elems, dtype=self.act_dtype, device=device)
         self.workspace = torch.zeros(e.workspace_elems, **f32)
-        e.bind(self.params.data_ptr(), self.grads.data_ptr(), self.momentum.data_ptr(),
+        e.bind(self._params.data_ptr(), self.grads.data_ptr(), self._momentum.data_ptr(),
                self.bn_buffers.data_ptr() if cfg.batch_norm else 0, self.arena.data_ptr(),
                self.workspace.data_ptr())
         self.slots = list(e.param_slots)
@@ -100,6 +100,12 @@ class NativeBackend:
             # behind are final: no sync, or the bucket reducer (the two manual modes
             # synchronise after backward has ended)
             self._fuse_opt = bool(cfg.fused_optimizer) and e.wgrad_overlap and self.manual is None
+            # deep layers' update on the side stream, next to the first layers of the next forward
+            late = int(os.environ.get("DML_UPDATE_OVERLAP", cfg.update_overlap))
+            if late < 0:        # auto: from the first layer of the last spatial sizes (4x4 and below)
+                late = next((i for i, row in enumerate(e.layer_table) if row[2] <= 4), 0)
+            if e.wgrad_overlap and not self._fuse_opt and not cfg.use_graph:
+                e.set_update_overlap(min(late, e.num_conv))
         self._graph_ready = False
         self._x_static = None
         self._t_static = None
@@ -170,7 +176,7 @@ class NativeBackend:
                 grown = torch.zeros(e.param_elems + e.bn_elems, dtype=torch.float32,
                                     device=self.device)
                 self.grads = grown
-                e.bind(self.params.data_ptr(), self.grads.data_ptr(), self.momentum.data_ptr(),
+                e.bind(self._params.data_ptr(), self.grads.data_ptr(), self._momentum.data_ptr(),
                        self.bn_buffers.data_ptr(), self.arena.data_ptr(), self.workspace.data_ptr())
             slices = []
             for b, (lo, hi) in enumerate(buckets):
@@ -203,7 +209,7 @@ class NativeBackend:
                                              self.grads[e.param_elems:].data_ptr(), e.bn_elems)
             # what DistributedDataParallel's constructor does: everyone adopts rank 0's state
             if self.world > 1:
-                comm.broadcast(self.params, 0)
+                comm.broadcast(self._params, 0)
                 if cfg.batch_norm:
                     comm.broadcast(self.bn_buffers, 0)
                 self.engine.refresh_weights(self._stream())
@@ -242,6 +248,22 @@ class NativeBackend:
             self.manual.run(self._stream())
 
     # ------------------------------------------------------------------ steps
+    def _join_update(self) -> None:
+        """Order the current stream behind a deep-layer update still running on the side
+        stream (``VggEngine.set_update_overlap``) before the flat buffers are touched."""
+        if hasattr(self.engine, "join_update"):
+            self.engine.join_update(self._stream())
+
+    @property
+    def params(self) -> torch.Tensor:
+        self._join_update()
+        return self._params
+
+    @property
+    def momentum(self) -> torch.Tensor:
+        self._join_update()
+        return self._momentum
+
     @staticmethod
     def _stream() -> int:
         return int(torch.cuda.current_stream().cuda_stream)
