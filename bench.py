@@ -263,12 +263,15 @@ def run_rank(ns) -> None:
             comm.barrier(ns.comm_timeout)
         torch.cuda.synchronize()
 
+    host_loop = []      # per timed window: seconds until the LAST train_step call returned
+
     def timed(n, first=0):
         barrier()
         t = time.perf_counter()
         last = None
         for i in range(n):
             last = backend.train_step(*batches[(first + i) % len(batches)])
+        host_loop.append(time.perf_counter() - t)
         barrier()
         return time.perf_counter() - t, last
 
@@ -288,7 +291,7 @@ def run_rank(ns) -> None:
 
     # ---- everything below is outside the measured region
     windows = [timed(ns.steps)[0] for _ in range(max(ns.windows, 0))]
-    probe = 4                                   # host cost of enqueueing a step into an empty queue
+    probe = 20                                  # host cost of enqueueing steps into an empty queue
     t1 = time.perf_counter()
     for i in range(probe):
         backend.train_step(*batches[i % len(batches)])
@@ -347,6 +350,9 @@ def run_rank(ns) -> None:
                        "tail_bucket_cap_mb": ns.tail_bucket_cap_mb,
                        "sync_plan": backend.sync_plan() if hasattr(backend, "sync_plan") else None,
                        "host_enqueue_ms_per_step": round(host_elapsed / probe * 1e3, 4),
+                       # the measured window's calls had all returned after this long: equal to
+                       # ms_per_step = the host is the bottleneck, well below = the GPU is
+                       "host_loop_ms_per_step": round(host_loop[0] / ns.steps * 1e3, 4),
                        "final_loss": round(final_loss, 4), "overlap": overlap,
                        "baseline": f"reference {ns.mode}: {REFERENCE_IMAGES_PER_SEC[ns.mode]} "
                                    "images/s on its CPU cluster (group25.pdf)"}}

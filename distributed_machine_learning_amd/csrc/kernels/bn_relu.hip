@@ -97,26 +97,39 @@ __global__ __launch_bounds__(256) void bn_stats_finish_kernel(
 }
 
 namespace {
-// mean / rstd (+ running statistics) either from a pass over x or from partial sums a
-// producer kernel already left behind
+// The partial statistics rows of x: the ones a producer kernel already left behind, or those of
+// a pass over x (into ws, with the shift vector behind the slab).
 template <typename T>
-void batch_statistics(const T* x, float* ws, int rows, int c, float* save_mean,
-                      float* save_rstd, float* running_mean, float* running_var, float momentum,
-                      float eps, const BnPartials& from, hipStream_t stream) {
+BnPartials statistics_partials(const T* x, float* ws, int rows, int c, const BnPartials& from,
+                               hipStream_t stream) {
     if (from.data) {
         if (from.rows <= 0) throw std::invalid_argument("BatchNorm: empty partial sums");
-        hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
-                           from.data, save_mean, save_rstd, running_mean, running_var, from.rows,
-                           rows, c, momentum, eps, from.shift);
-        return;
+        return from;
     }
     const ColReducePlan pl = plan_col_reduce(rows, c);
     hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(pl.blocks), dim3(256), 0, stream, x, ws, rows, c,
                        pl.rows_per_block);
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
-                       (const float*)ws, save_mean, save_rstd, running_mean, running_var, pl.blocks,
-                       rows, c, momentum, eps, (const float*)(ws + kColReduceSlabFloats));
+    BnPartials out;
+    out.data = ws;
+    out.rows = pl.blocks;
+    out.shift = ws + kColReduceSlabFloats;
+    return out;
 }
+
+// mean / rstd (+ running statistics) from the partial rows, as a launch of its own
+void finish_statistics(const BnPartials& part, int rows, int c, float* save_mean, float* save_rstd,
+                       float* running_mean, float* running_var, float momentum, float eps,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream, part.data,
+                       save_mean, save_rstd, running_mean, running_var, part.rows, rows, c, momentum,
+                       eps, part.shift);
+}
+
+// fold + apply in one launch when the partial rows are few enough (defined with its kernel below)
+template <typename T>
+bool fold_apply_plain(const T* x, T* y, const float* gamma, const float* beta, const BnPartials& part,
+                      float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                      int rows, int c, float momentum, float eps, hipStream_t stream);
 }  // namespace
 
 // y = relu(x * scale + shift) with scale = gamma * rstd, shift = beta - mean * scale.  A
@@ -166,8 +179,12 @@ void bn_fwd_train_launch(const T* x, T* y, const float* gamma, const float* beta
                          float* save_rstd, float* ws, int rows, int c, float momentum, float eps,
                          hipStream_t stream, BnPartials from) {
     check(rows, c, "bn_relu_fwd_train");
-    batch_statistics(x, ws, rows, c, save_mean, save_rstd, running_mean, running_var, momentum, eps,
-                     from, stream);
+    const BnPartials part = statistics_partials(x, ws, rows, c, from, stream);
+    if (fold_apply_plain(x, y, gamma, beta, part, save_mean, save_rstd, running_mean, running_var,
+                         rows, c, momentum, eps, stream))
+        return;
+    finish_statistics(part, rows, c, save_mean, save_rstd, running_mean, running_var, momentum, eps,
+                      stream);
     const size_t total8 = (size_t)rows * (c / 8);
     hipLaunchKernelGGL((bn_apply_kernel<false, T>), dim3(apply_blocks(total8)), dim3(256), 0, stream,
                        x, y, gamma, beta, (const float*)save_mean, (const float*)save_rstd, c, eps,
@@ -694,6 +711,130 @@ bool bn_relu_bwd_small(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const floa
 
 bool bn_bwd_single_launch(int dy_rows, int c) { return use_slab_kernel(dy_rows, c); }
 
+// ------------------------------------- forward, training: fold + apply in ONE launch
+// The fold of the partial statistics rows used to be a launch of its own between the producer
+// and the apply pass - a few microseconds of kernel plus a dependent-launch gap on the critical
+// path of every layer.  Here every block of the apply pass folds the rows itself, for the 32
+// channels it works on only (grid.y = channel slices, so a block reads nb x 64 floats, not
+// nb x 2c): 64 columns x 4 row parts per block, summed in a fixed order.  The blocks of the
+// first row chunk also store mean / rstd for backward and move the running statistics.
+constexpr int kFoldSlice = 32;          // channels per block
+constexpr int kFoldMaxRows = 128;       // partial rows up to which the fold rides in the apply pass
+
+template <bool POOL, typename T>
+__global__ __launch_bounds__(256) void bn_fold_apply_kernel(
+    const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ partials, int nb,
+    const float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_rstd,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int stat_rows,
+    float momentum, float eps, int c, PoolGeom geo, int out_rows) {
+    __shared__ float part[4][2 * kFoldSlice];
+    const int tid = threadIdx.x;
+    const int col0 = blockIdx.y * kFoldSlice;
+    {
+        const int j = tid & 63, pt = tid >> 6;          // column j = stat * 32 + channel
+        const float* src = partials + (size_t)(j >> 5) * c + col0 + (j & 31);
+        // every row of this thread in flight at once: the rows were written by another kernel,
+        // possibly through another XCD's L2, and a dependent round trip costs more than the rest
+        float v[kFoldMaxRows / 4];
+#pragma unroll
+        for (int q = 0; q < kFoldMaxRows / 4; ++q) {
+            const int k = pt + 4 * q;
+            v[q] = k < nb ? src[(size_t)k * 2 * c] : 0.f;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < kFoldMaxRows / 4; ++q) acc += v[q];
+        part[pt][j] = acc;
+    }
+    __syncthreads();
+    const int cgl = tid & 3, rl = tid >> 2;             // 4 column groups x 64 row lanes
+    const int col = col0 + cgl * 8;
+    float sc[8], sh[8];
+    {
+        const float inv_n = 1.f / (float)stat_rows;
+        float g[8], bb[8];
+        load_consts(gamma, col, g);
+        load_consts(beta, col, bb);
+        const bool writer = blockIdx.x == 0 && rl == 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ch = cgl * 8 + k;
+            const float s1 = (part[0][ch] + part[1][ch]) + (part[2][ch] + part[3][ch]);
+            const float s2 = (part[0][kFoldSlice + ch] + part[1][kFoldSlice + ch]) +
+                             (part[2][kFoldSlice + ch] + part[3][kFoldSlice + ch]);
+            const float m0 = s1 * inv_n;
+            const float var = fmaxf(s2 * inv_n - m0 * m0, 0.f);
+            // the sums are of x - shift: a shift only moves the mean
+            const float mean = shift ? m0 + shift[col + k] : m0;
+            const float rs = rsqrtf(var + eps);
+            sc[k] = g[k] * rs;
+            sh[k] = bb[k] - mean * sc[k];
+            if (writer) {
+                save_mean[col + k] = mean;
+                save_rstd[col + k] = rs;
+                if (running_mean) {
+                    const float unbiased =
+                        stat_rows > 1 ? var * ((float)stat_rows / (float)(stat_rows - 1)) : var;
+                    running_mean[col + k] = (1.f - momentum) * running_mean[col + k] + momentum * mean;
+                    running_var[col + k] = (1.f - momentum) * running_var[col + k] + momentum * unbiased;
+                }
+            }
+        }
+    }
+    for (int r = blockIdx.x * 64 + rl; r < out_rows; r += gridDim.x * 64) {
+        float o[8];
+        if constexpr (POOL) {
+            float v[4][8];
+            load_window(x, geo.in_pixel((size_t)r), col >> 3, c, geo.hw, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float z0 = __builtin_fmaf(v[0][k], sc[k], sh[k]);
+                const float z1 = __builtin_fmaf(v[1][k], sc[k], sh[k]);
+                const float z2 = __builtin_fmaf(v[2][k], sc[k], sh[k]);
+                const float z3 = __builtin_fmaf(v[3][k], sc[k], sh[k]);
+                o[k] = fmaxf(fmaxf(fmaxf(z0, z1), fmaxf(z2, z3)), 0.f);
+            }
+        } else {
+            float v[8];
+            load8(x + (size_t)r * c + col, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = fmaxf(__builtin_fmaf(v[k], sc[k], sh[k]), 0.f);
+        }
+        store8(y + (size_t)r * c + col, o);
+    }
+}
+
+namespace {
+// grid of the fused pass: channel slices x row chunks, 1-4 rows per thread, ~512 blocks
+dim3 fold_apply_grid(int out_rows, int c) {
+    const int slices = c / kFoldSlice;
+    long long per_thread = (long long)out_rows * slices / (64LL * 512);
+    per_thread = per_thread < 1 ? 1 : per_thread > 4 ? 4 : per_thread;
+    const int chunks = (int)((out_rows + 64 * per_thread - 1) / (64 * per_thread));
+    return dim3(chunks < 1 ? 1 : chunks, slices);
+}
+bool fold_in_apply(int nb, int c) { return nb > 0 && nb <= kFoldMaxRows && c % kFoldSlice == 0; }
+
+template <typename T>
+bool fold_apply_plain(const T* x, T* y, const float* gamma, const float* beta, const BnPartials& part,
+                      float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                      int rows, int c, float momentum, float eps, hipStream_t stream) {
+    if (!fold_in_apply(part.rows, c)) return false;
+    const PoolGeom none = {c / 8, 0, 0};
+    hipLaunchKernelGGL((bn_fold_apply_kernel<false, T>), fold_apply_grid(rows, c), dim3(256), 0,
+                       stream, x, y, gamma, beta, part.data, part.rows, part.shift, save_mean,
+                       save_rstd, running_mean, running_var, rows, momentum, eps, c, none, rows);
+    return true;
+}
+template bool fold_apply_plain<uint16_t>(const uint16_t*, uint16_t*, const float*, const float*,
+                                         const BnPartials&, float*, float*, float*, float*, int, int,
+                                         float, float, hipStream_t);
+template bool fold_apply_plain<float>(const float*, float*, const float*, const float*,
+                                      const BnPartials&, float*, float*, float*, float*, int, int,
+                                      float, float, hipStream_t);
+}  // namespace
+
 namespace {
 PoolGeom pool_geom(int batch, int hw, int c, const char* who) {
     if (batch <= 0 || hw < 2 || hw > 64 || (hw & (hw - 1)))
@@ -711,8 +852,16 @@ void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, 
     const int rows = batch * hw * hw;
     check(rows, c, "bn_relu_pool_fwd_train");
     const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_fwd_train");
-    batch_statistics(x, ws, rows, c, save_mean, save_rstd, running_mean, running_var, momentum, eps,
-                     from, stream);
+    const BnPartials part = statistics_partials(x, ws, rows, c, from, stream);
+    if (fold_in_apply(part.rows, c)) {
+        hipLaunchKernelGGL((bn_fold_apply_kernel<true, uint16_t>), fold_apply_grid(rows / 4, c),
+                           dim3(256), 0, stream, x, y, gamma, beta, part.data, part.rows, part.shift,
+                           save_mean, save_rstd, running_mean, running_var, rows, momentum, eps, c,
+                           geo, rows / 4);
+        return;
+    }
+    finish_statistics(part, rows, c, save_mean, save_rstd, running_mean, running_var, momentum, eps,
+                      stream);
     const size_t total8 = (size_t)(rows / 4) * (c / 8);
     hipLaunchKernelGGL(bn_apply_pool_kernel<false>, dim3(apply_blocks(total8)), dim3(256), 0,
                        stream, x, y, gamma, beta, (const float*)save_mean,
