@@ -358,6 +358,13 @@ bool bn_relu_bwd_small(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const floa
                        float* dgamma, float* dbeta, int rows, int c, hipStream_t stream,
                        SplitSlabs sl);
 
+// (fold + apply in one launch when the reduction left few enough partial rows; defined with its
+// kernel further down)
+bool bn_bwd_fold_apply_plain(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+                             const float* beta, const float* save_mean, const float* save_rstd,
+                             const float* partials, int nb, float* dgamma, float* dbeta, int rows,
+                             int c, hipStream_t stream);
+
 void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
                  const float* beta, const float* save_mean, const float* save_rstd,
                  float* dgamma, float* dbeta, float* ws, int rows, int c, hipStream_t stream,
@@ -375,6 +382,9 @@ void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gam
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, uint16_t>), dim3(pl.blocks), dim3(256), 0,
                            stream, x, dy, gamma, beta, save_mean, save_rstd, ws, rows, c,
                            pl.rows_per_block, sl);
+    if (bn_bwd_fold_apply_plain(x, dy, dx, gamma, beta, save_mean, save_rstd, ws, pl.blocks, dgamma,
+                                dbeta, rows, c, stream))
+        return;
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
                        (const float*)ws, dgamma, dbeta, pl.blocks, c);
     const size_t total8 = (size_t)rows * (c / 8);
@@ -845,6 +855,126 @@ PoolGeom pool_geom(int batch, int hw, int c, const char* who) {
 }
 }  // namespace
 
+// ------------------------------------------ backward: fold + apply in ONE launch
+// The mirror image of bn_fold_apply_kernel: every block of the apply pass folds the partial rows
+// of dbeta / dgamma for its own 32 channels (up to 256 rows: 64 loads per thread, all in flight),
+// the blocks of the first row chunk store the two gradients, then the tensor is streamed once.
+constexpr int kBwdFoldMaxRows = 256;
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_fold_apply_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ partials, int nb, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int stat_rows, int c, PoolGeom geo, int out_rows) {
+    __shared__ float part[4][2 * kFoldSlice];
+    const int tid = threadIdx.x;
+    const int col0 = blockIdx.y * kFoldSlice;
+    {
+        const int j = tid & 63, pt = tid >> 6;
+        const float* src = partials + (size_t)(j >> 5) * c + col0 + (j & 31);
+        float v[kBwdFoldMaxRows / 4];
+#pragma unroll
+        for (int q = 0; q < kBwdFoldMaxRows / 4; ++q) {
+            const int k = pt + 4 * q;
+            v[q] = k < nb ? src[(size_t)k * 2 * c] : 0.f;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < kBwdFoldMaxRows / 4; ++q) acc += v[q];
+        part[pt][j] = acc;
+    }
+    __syncthreads();
+    const int cgl = tid & 3, rl = tid >> 2;
+    const int col = col0 + cgl * 8;
+    const float inv_n = 1.f / (float)stat_rows;
+    float ysc[8], ysh[8], k1[8], k2[8], k3[8];
+    {
+        float gm[8], bt[8], mn[8], rs[8];
+        load_consts(gamma, col, gm); load_consts(beta, col, bt);
+        load_consts(mean, col, mn); load_consts(rstd, col, rs);
+        const bool writer = blockIdx.x == 0 && rl == 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ch = cgl * 8 + k;
+            const float db_sum = (part[0][ch] + part[1][ch]) + (part[2][ch] + part[3][ch]);
+            const float dg_sum = (part[0][kFoldSlice + ch] + part[1][kFoldSlice + ch]) +
+                                 (part[2][kFoldSlice + ch] + part[3][kFoldSlice + ch]);
+            if (writer) {
+                dbeta[col + k] = db_sum;
+                dgamma[col + k] = dg_sum;
+            }
+            const float mrs = mn[k] * rs[k];
+            const float dg = dg_sum * inv_n, db = db_sum * inv_n;
+            ysc[k] = gm[k] * rs[k];
+            k1[k] = gm[k] * rs[k];
+            if (POOL) {     // (the pooled kernels' forms of the same constants, bit for bit)
+                ysh[k] = __builtin_fmaf(-gm[k], mrs, bt[k]);
+                k2[k] = k1[k] * __builtin_fmaf(-mrs, dg, db);
+                k3[k] = (k1[k] * rs[k]) * dg;
+            } else {
+                ysh[k] = bt[k] - mn[k] * ysc[k];
+                k2[k] = k1[k] * (db - mrs * dg);
+                k3[k] = k1[k] * rs[k] * dg;
+            }
+        }
+    }
+    for (int r = blockIdx.x * 64 + rl; r < out_rows; r += gridDim.x * 64) {
+        float g[8];
+        unpack8(*(const uint4*)(dy + (size_t)r * c + col), g);
+        if constexpr (POOL) {
+            float v[4][8], o[4][8];
+            const size_t ipix = geo.in_pixel((size_t)r);
+            load_window(x, ipix, col >> 3, c, geo.hw, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                bool live;
+                const int w = window_winner(__builtin_fmaf(v[0][k], ysc[k], ysh[k]),
+                                            __builtin_fmaf(v[1][k], ysc[k], ysh[k]),
+                                            __builtin_fmaf(v[2][k], ysc[k], ysh[k]),
+                                            __builtin_fmaf(v[3][k], ysc[k], ysh[k]), live);
+                const float gk = live ? k1[k] * g[k] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    o[q][k] = __builtin_fmaf(-k3[k], v[q][k], (w == q ? gk : 0.f) - k2[k]);
+            }
+            uint16_t* p = dx + ipix * c + col;
+            *(uint4*)(p) = pack8(o[0]);
+            *(uint4*)(p + c) = pack8(o[1]);
+            *(uint4*)(p + (size_t)geo.hw * c) = pack8(o[2]);
+            *(uint4*)(p + (size_t)geo.hw * c + c) = pack8(o[3]);
+        } else {
+            float v[8], o[8];
+            unpack8(*(const uint4*)(x + (size_t)r * c + col), v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gi = (__builtin_fmaf(v[k], ysc[k], ysh[k]) > 0.f) ? g[k] : 0.f;
+                o[k] = k1[k] * gi - k2[k] - k3[k] * v[k];
+            }
+            *(uint4*)(dx + (size_t)r * c + col) = pack8(o);
+        }
+    }
+}
+
+namespace {
+bool fold_in_bwd_apply(int nb, int c) {
+    return nb > 0 && nb <= kBwdFoldMaxRows && c % kFoldSlice == 0;
+}
+}  // namespace
+
+bool bn_bwd_fold_apply_plain(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+                             const float* beta, const float* save_mean, const float* save_rstd,
+                             const float* partials, int nb, float* dgamma, float* dbeta, int rows,
+                             int c, hipStream_t stream) {
+    if (!fold_in_bwd_apply(nb, c)) return false;
+    const PoolGeom none = {c / 8, 0, 0};
+    hipLaunchKernelGGL(bn_bwd_fold_apply_kernel<false>, fold_apply_grid(rows, c), dim3(256), 0, stream,
+                       x, dy, dx, gamma, beta, save_mean, save_rstd, partials, nb, dgamma, dbeta,
+                       rows, c, none, rows);
+    return true;
+}
+
 void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float* save_mean,
                             float* save_rstd, float* ws, int batch, int hw, int c, float momentum,
@@ -909,6 +1039,12 @@ void bn_relu_pool_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float
         hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<false>, dim3(pl.blocks), dim3(256), 0, stream,
                            x, dy, gamma, beta, save_mean, save_rstd, ws, out_rows, c,
                            pl.rows_per_block, geo, sl);
+    }
+    if (dx && fold_in_bwd_apply(nb, c)) {
+        hipLaunchKernelGGL(bn_bwd_fold_apply_kernel<true>, fold_apply_grid(out_rows, c), dim3(256), 0,
+                           stream, x, (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd,
+                           partials, nb, dgamma, dbeta, rows, c, geo, out_rows);
+        return;
     }
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream, partials,
                        dgamma, dbeta, nb, c);

@@ -458,7 +458,9 @@ def test_conv1_wgrad_with_bn_pool_backward_on_the_fly(batch):
     g, dgamma_a, dbeta_a = n.bn_relu_pool_bwd(pre, dy, gamma, beta, mean, rstd)
     dw_a, _ = n.conv1_wgrad(x4, g)
     dw_b, dgamma_b, dbeta_b = n.conv1_wgrad_bn_pool(x4, pre, dy, gamma, beta, mean, rstd)
-    assert torch.equal(dgamma_a, dgamma_b) and torch.equal(dbeta_a, dbeta_b)
+    # (the same partial sums folded in two orders: inside the apply pass / by the fold kernel)
+    torch.testing.assert_close(dgamma_a, dgamma_b, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(dbeta_a, dbeta_b, rtol=1e-5, atol=1e-4)
     check("conv1 wgrad fused vs stored gradient", dw_b, dw_a, rtol=1e-4, atol_scale=1e-4)
     # against autograd on the bf16-rounded operands
     wr = w.to(torch.bfloat16).float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
