@@ -9,7 +9,6 @@
 // candidate; the candidate is kept only if the empty kernel did not have to wait.
 #include <chrono>
 #include <cstdio>
-#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -52,12 +51,9 @@ hipStream_t create_concurrent_stream(const std::vector<hipStream_t>& avoid, int 
     hipStream_t found = nullptr;
     for (int t = 0; t < max_tries && !found; ++t) {
         hipStream_t s = nullptr;
-        // tuning switch DML_SIDE_PRIORITY: -1 high, 0 default, 1 low (queue arbitration)
-        const char* pr = getenv("DML_SIDE_PRIORITY");
-        if (pr && *pr)
-            check(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, atoi(pr)), "hipStreamCreate");
-        else
-            check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+        // (plain streams on purpose: a low- or high-priority side stream measured no different,
+        // and a CU-masked one (hipExtStreamCreateWithCUMask) more than doubled the step time)
+        check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
         bool ok = true;
         for (hipStream_t a : avoid)
             if (!streams_run_concurrently(a, s)) { ok = false; break; }
