@@ -17,6 +17,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <cstdlib>
 #include <functional>
 #include <stdexcept>
 
@@ -262,6 +263,11 @@ void VggEngine::join_update(hipStream_t stream) {
 
 void VggEngine::set_fused_optimizer(bool on, float lr, float momentum, float weight_decay,
                                     float grad_scale) {
+    // per-layer slices from the first 4x4 layer on (see backward)
+    opt_slice_from_ = (int)convs_.size();
+    for (size_t i = 0; i < convs_.size(); ++i)
+        if (convs_[i].hw <= 4) { opt_slice_from_ = (int)i; break; }
+    if (const char* e = getenv("DML_OPT_SLICE_FROM")) opt_slice_from_ = atoi(e);   // tuning
     opt_.on = on; opt_.lr = lr; opt_.mu = momentum; opt_.wd = weight_decay; opt_.gscale = grad_scale;
 }
 
@@ -634,11 +640,13 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                         reducer_->bucket_ready(b, wgrad_stream_, bucket_update(b));
                 owed.clear();
             }
-            if (fuse_opt && !reducer_ && i <= 1) {
-                // The side stream's last hand-off: behind its sums the gradients of every layer
-                // but the first are final, and it would idle while the main stream finishes
-                // the first layer - one update launch for all of them here.  (Slices after
-                // every group were measured slower: they delay the weight gradients behind them.)
+            if (fuse_opt && !reducer_ && (i >= opt_slice_from_ || i <= 1)) {
+                // Behind this hand-off's sums the gradients of layers i.. are final.  The deep
+                // layers (most of the parameters) are updated at once: early in backward the side
+                // stream waits for hand-offs most of the time and the update fills those gaps.
+                // From opt_slice_from_ down the side stream is as busy as the main chain, so the
+                // remaining (small) layers wait for its last hand-off, where it would idle while
+                // the main stream finishes the first layer.
                 sgd_slice(layer_begin(i), layer_begin(updated_above), wgrad_stream_);
                 updated_above = i;
             }

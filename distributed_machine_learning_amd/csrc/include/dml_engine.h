@@ -192,6 +192,7 @@ class VggEngine {
     bool wgrad_overlap_ = false;
     struct { bool on = false; float lr = 0, mu = 0, wd = 0, gscale = 1; } opt_;
     bool opt_applied_ = false;      // this step's update already happened inside backward
+    int opt_slice_from_ = 0;        // fused update: layers >= this get a slice right behind their sums
     std::vector<BucketRange> bucket_ranges_;
     hipStream_t wgrad_stream_ = nullptr;
     int wgrad_group_ = 2;
