@@ -93,6 +93,26 @@ void VggEngineF32::bind(float* params, float* grads, float* momentum, float* bn_
     arena_ = arena; ws_ = workspace;
 }
 
+VggEngineF32::~VggEngineF32() {
+    for (hipEvent_t e : grad_ready_) (void)hipEventDestroy(e);
+    if (side_done_) (void)hipEventDestroy(side_done_);
+    if (side_) (void)hipStreamDestroy(side_);
+}
+
+void VggEngineF32::set_wgrad_overlap(bool on, hipStream_t compute_stream) {
+    if (on && !side_) {
+        // a hardware queue of its own, or the two streams run in line (see stream_probe.hip)
+        std::vector<hipStream_t> avoid = {compute_stream};
+        if (reducer_ && reducer_->comm_stream()) avoid.push_back(reducer_->comm_stream());
+        side_ = create_concurrent_stream(avoid);
+        grad_ready_.resize(lay_.convs.size());
+        for (hipEvent_t& e : grad_ready_)
+            check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&side_done_, hipEventDisableTiming), "hipEventCreate");
+    }
+    overlap_ = on;
+}
+
 void VggEngineF32::set_reducer(BucketReducer* reducer, const std::vector<BucketRange>& buckets) {
     reducer_ = reducer;
     buckets_by_layer_.assign(lay_.convs.size() + 1, {});
@@ -224,35 +244,53 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
             bn_relu_bwd(arena_ + b.pre_off, src, g, params_ + c.gamma_off, params_ + c.beta_off,
                         ws_ + b.save_off, ws_ + b.save_off + c.cout, grads_ + c.gamma_off,
                         grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream);
-        if (i == 0) {
-            // Conv bias gradient under BatchNorm: exactly zero in exact arithmetic (the
-            // normalisation removes any per-channel offset), left at the buffer's zero.
-            conv1_wgrad_f32(x, g, grads_ + c.w_off, bn_ ? nullptr : grads_ + c.b_off, batch,
-                            ws_ + c1_ws_off_, stream);
-        } else {
-            const ParamLayout::Conv& prev = lay_.convs[i - 1];
-            const float* in = arena_ + (prev.pool_after ? buf_[i - 1].pool_off : buf_[i - 1].out_off);
-            if (!bn_) column_sum(g, grads_ + c.b_off, rows, c.cout, ws_ + stats_off_, stream);
-            const ConvShape s = {batch, c.hw, c.cin, c.cout};
-            conv3x3_wgrad_f32(in, g, grads_ + c.w_off, s, ws_ + b.wslab_off, stream);
-            const int splits = conv3x3_wgrad_f32_splits(s);
-            if (splits > 1) {
-                if (sums_.n == SlabSumJobs::kMax) flush_sums(stream);
-                const int j = sums_.n++;
-                sums_.src_off[j] = b.wslab_off;
-                sums_.dst_off[j] = c.w_off;
-                sums_.count[j] = (size_t)c.cout * 9 * c.cin;
-                sums_.splits[j] = splits;
-            }
+        // g is complete: from here the weight gradient (side stream when overlapping) and the
+        // input gradient (main stream) are independent.  The main chain is enqueued first.
+        hipStream_t wstream = stream;
+        if (overlap_) {
+            check_hip(hipEventRecord(grad_ready_[i], stream), "hipEventRecord(grad ready)");
+            wstream = side_;
+        }
+        if (i > 0) {
             // input gradient; the producer's ReLU is folded in when nothing sits in between
             const bool fold = direct(i - 1);
             conv3x3_igemm_f32(g, arena_ + b.wd_off, arriving(i - 1), nullptr,
                               fold ? arena_ + buf_[i - 1].out_off : nullptr,
                               {batch, c.hw, c.cout, c.cin}, fold ? EPI_MASK : EPI_NONE, stream);
         }
-        fire_buckets(i, stream);
+        if (overlap_)
+            check_hip(hipStreamWaitEvent(side_, grad_ready_[i], 0), "hipStreamWaitEvent(grad ready)");
+        if (i == 0) {
+            // Conv bias gradient under BatchNorm: exactly zero in exact arithmetic (the
+            // normalisation removes any per-channel offset), left at the buffer's zero.
+            conv1_wgrad_f32(x, g, grads_ + c.w_off, bn_ ? nullptr : grads_ + c.b_off, batch,
+                            ws_ + c1_ws_off_, wstream);
+        } else {
+            const ParamLayout::Conv& prev = lay_.convs[i - 1];
+            const float* in = arena_ + (prev.pool_after ? buf_[i - 1].pool_off : buf_[i - 1].out_off);
+            // (the reduction scratch is free: BatchNorm, its other user, is off in this case)
+            if (!bn_) column_sum(g, grads_ + c.b_off, rows, c.cout, ws_ + stats_off_, wstream);
+            const ConvShape s = {batch, c.hw, c.cin, c.cout};
+            conv3x3_wgrad_f32(in, g, grads_ + c.w_off, s, ws_ + b.wslab_off, wstream);
+            const int splits = conv3x3_wgrad_f32_splits(s);
+            if (splits > 1) {
+                if (sums_.n == SlabSumJobs::kMax) flush_sums(wstream);
+                const int j = sums_.n++;
+                sums_.src_off[j] = b.wslab_off;
+                sums_.dst_off[j] = c.w_off;
+                sums_.count[j] = (size_t)c.cout * 9 * c.cin;
+                sums_.splits[j] = splits;
+            }
+        }
+        // a bucket leaves from the stream that completed it (the BatchNorm gradients it may hold
+        // were written on the main stream before grad_ready_[i])
+        fire_buckets(i, wstream);
     }
-    flush_sums(stream);
+    flush_sums(overlap_ ? side_ : stream);
+    if (overlap_) {
+        check_hip(hipEventRecord(side_done_, side_), "hipEventRecord(side done)");
+        check_hip(hipStreamWaitEvent(stream, side_done_, 0), "hipStreamWaitEvent(side done)");
+    }
 }
 
 void VggEngineF32::forward_backward(const float* x, const int64_t* target, int batch,
@@ -326,6 +364,11 @@ void bind_engine_f32(py::module_& m) {
         }, py::keep_alive<1, 2>())
         .def("set_manual_sync", [](VggEngineF32& e, ManualSync* m) { e.set_manual_sync(m); },
              py::keep_alive<1, 2>())
+        .def("set_wgrad_overlap", [](VggEngineF32& e, bool on, uintptr_t compute_stream) {
+            e.set_wgrad_overlap(on, (hipStream_t)compute_stream);
+        }, py::arg("on"), py::arg("compute_stream") = 0)
+        .def_property_readonly("wgrad_overlap", &VggEngineF32::wgrad_overlap)
+        .def_property_readonly("wgrad_stream", [](VggEngineF32& e) { return (uintptr_t)e.wgrad_stream(); })
         .def("refresh_weights", [](VggEngineF32& e, uintptr_t s) { e.refresh_weights((hipStream_t)s); })
         .def("forward", [](VggEngineF32& e, uintptr_t x, int batch, bool training, uintptr_t s) {
             e.forward((const float*)x, batch, training, (hipStream_t)s);

@@ -245,6 +245,13 @@ class VggEngineF32 {
     void train_step(const float* x_nhwc4, const int64_t* target, int batch, float lr,
                     float momentum, float weight_decay, float grad_scale, hipStream_t stream);
     void eval_step(const float* x_nhwc4, const int64_t* target, int batch, hipStream_t stream);
+    // Weight gradients (with bias gradients, slab sums and the buckets they complete) on a second
+    // HIP stream next to the pool / BatchNorm / backward-data chain, one event per layer; the
+    // main stream joins it at the end of backward.  Same kernels on the same values.
+    void set_wgrad_overlap(bool on, hipStream_t compute_stream = nullptr);
+    bool wgrad_overlap() const { return overlap_; }
+    hipStream_t wgrad_stream() const { return side_; }
+    ~VggEngineF32();
 
   private:
     struct Buffers {
@@ -268,6 +275,10 @@ class VggEngineF32 {
     std::vector<std::vector<int>> buckets_by_layer_;
     SlabSumJobs sums_;
     long long bn_steps_ = 0;
+    bool overlap_ = false;
+    hipStream_t side_ = nullptr;
+    std::vector<hipEvent_t> grad_ready_;    // per layer: dL/d(conv output) complete on the main stream
+    hipEvent_t side_done_ = nullptr;
 };
 
 void bind_engine(pybind11::module_& m);

@@ -91,8 +91,11 @@ class NativeBackend:
         # per hand-off measured best with and without a reducer (0.712 vs 0.732 ms with one)
         group = int(cfg.wgrad_group) or 1
         if self.fp32:
-            # the fp32 step is bound by the convolutions' arithmetic: one stream, no fusion
+            # the fp32 step is bound by the convolutions' arithmetic: no optimizer fusion, and the
+            # weight gradients go to a side stream only to fill the tails of the other kernels
             self._fuse_opt = False
+            e.set_wgrad_overlap(bool(cfg.wgrad_overlap) and not cfg.serialize_streams,
+                                self._stream())
         else:
             e.set_wgrad_overlap(bool(cfg.wgrad_overlap) and not cfg.serialize_streams, group,
                                 self._stream())

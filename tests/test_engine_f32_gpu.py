@@ -236,6 +236,37 @@ def test_fp32_eval_checkpoint_and_bit_reproducibility(tmp_path):
     assert int(correct) == int((logits_ref.argmax(1) == t).sum())
 
 
+@pytest.mark.parametrize("batch_norm", [False, True])
+def test_fp32_wgrad_side_stream_matches_single_stream(batch_norm):
+    """Weight gradients on the side stream (the default), with and without the bucket reducer,
+    against the serialized single-stream schedule: the race detector of the fp32 engine.  Every
+    kernel is deterministic, so any difference is a missing dependency."""
+    from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
+    comm = RcclCommunicator("127.0.0.1:29660" if batch_norm else "127.0.0.1:29661", 0, 1, 0,
+                            timeout_s=60)
+    try:
+        serial, _ = _mk(batch_norm, 64, wgrad_overlap=False)
+        side, _ = _mk(batch_norm, 64, wgrad_overlap=True)
+        ddp, _ = _mk(batch_norm, 64, wgrad_overlap=True, sync="ddp", comm=comm, bucket_cap_mb=2.0)
+        ddp_serial, _ = _mk(batch_norm, 64, sync="ddp", comm=comm, bucket_cap_mb=2.0,
+                            serialize_streams=True)
+        assert side.engine.wgrad_overlap and not serial.engine.wgrad_overlap
+        assert not ddp_serial.engine.wgrad_overlap
+        for step in range(4):
+            _, x4, t = _batch(64, seed=step)
+            want = float(serial.train_step(x4, t).item())
+            for other in (side, ddp, ddp_serial):
+                assert float(other.train_step(x4, t).item()) == want
+        comm.guard_sync(30)
+        for other in (side, ddp, ddp_serial):
+            assert torch.equal(other.params, serial.params)
+            assert torch.equal(other.bn_buffers, serial.bn_buffers)
+        ddp.close()
+        ddp_serial.close()
+    finally:
+        comm.destroy()
+
+
 @pytest.mark.parametrize("sync", ["gather_scatter", "all_reduce", "ddp"])
 def test_fp32_sync_modes_world1(sync):
     from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
