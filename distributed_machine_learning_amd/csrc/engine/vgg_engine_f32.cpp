@@ -96,6 +96,8 @@ void VggEngineF32::bind(float* params, float* grads, float* momentum, float* bn_
 VggEngineF32::~VggEngineF32() {
     for (hipEvent_t e : grad_ready_) (void)hipEventDestroy(e);
     if (side_done_) (void)hipEventDestroy(side_done_);
+    if (updated_) (void)hipEventDestroy(updated_);
+    if (repack_done_) (void)hipEventDestroy(repack_done_);
     if (side_) (void)hipStreamDestroy(side_);
 }
 
@@ -109,6 +111,8 @@ void VggEngineF32::set_wgrad_overlap(bool on, hipStream_t compute_stream) {
         for (hipEvent_t& e : grad_ready_)
             check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
         check_hip(hipEventCreateWithFlags(&side_done_, hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&updated_, hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&repack_done_, hipEventDisableTiming), "hipEventCreate");
     }
     overlap_ = on;
 }
@@ -141,8 +145,15 @@ void VggEngineF32::flush_sums(hipStream_t stream) {
     sums_.n = 0;
 }
 
+void VggEngineF32::join_repack(hipStream_t stream) {
+    if (!repack_pending_) return;
+    check_hip(hipStreamWaitEvent(stream, repack_done_, 0), "hipStreamWaitEvent(repack)");
+    repack_pending_ = false;
+}
+
 void VggEngineF32::refresh_weights(hipStream_t stream) {
     if (!params_) throw std::logic_error("VggEngineF32: bind() first");
+    join_repack(stream);        // (a repack of the previous update may still run on the side stream)
     for (size_t i = 1; i < lay_.convs.size(); ++i) {
         const ParamLayout::Conv& c = lay_.convs[i];
         repack_dgrad_weights_f32(params_ + c.w_off, arena_ + buf_[i].wd_off, c.cout, c.cin, stream);
@@ -207,6 +218,9 @@ void VggEngineF32::forward(const float* x, int batch, bool training, hipStream_t
 void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hipStream_t stream) {
     TraceRange range("backward");
     const int nconv = (int)lay_.convs.size();
+    // the backward-data weight layouts of the last update were written on the side stream while
+    // forward ran (see optimizer_step)
+    join_repack(stream);
     sums_.n = 0;
     float* ta = arena_ + ta_off_;
     float* tb = arena_ + tb_off_;
@@ -315,7 +329,20 @@ void VggEngineF32::optimizer_step(float lr, float momentum, float weight_decay, 
     if (reducer_ && reducer_->take_pending_buffers(&bsrc, &bdst, &bn))
         check_hip(hipMemcpyAsync(bdst, bsrc, bn * sizeof(float), hipMemcpyDeviceToDevice, stream),
                   "hipMemcpyAsync(buffers)");
-    refresh_weights(stream);
+    if (overlap_) {
+        // Only backward reads the repacked weights: lay them out on the side stream, next to
+        // the forward pass of the following step.
+        check_hip(hipEventRecord(updated_, stream), "hipEventRecord(updated)");
+        check_hip(hipStreamWaitEvent(side_, updated_, 0), "hipStreamWaitEvent(updated)");
+        for (size_t i = 1; i < lay_.convs.size(); ++i) {
+            const ParamLayout::Conv& c = lay_.convs[i];
+            repack_dgrad_weights_f32(params_ + c.w_off, arena_ + buf_[i].wd_off, c.cout, c.cin, side_);
+        }
+        check_hip(hipEventRecord(repack_done_, side_), "hipEventRecord(repack)");
+        repack_pending_ = true;
+    } else {
+        refresh_weights(stream);
+    }
 }
 
 void VggEngineF32::train_step(const float* x, const int64_t* target, int batch, float lr,

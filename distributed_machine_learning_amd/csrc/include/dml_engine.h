@@ -278,7 +278,9 @@ class VggEngineF32 {
     bool overlap_ = false;
     hipStream_t side_ = nullptr;
     std::vector<hipEvent_t> grad_ready_;    // per layer: dL/d(conv output) complete on the main stream
-    hipEvent_t side_done_ = nullptr;
+    hipEvent_t side_done_ = nullptr, updated_ = nullptr, repack_done_ = nullptr;
+    bool repack_pending_ = false;           // weight layouts of the last update still on the side stream
+    void join_repack(hipStream_t stream);
 };
 
 void bind_engine(pybind11::module_& m);
