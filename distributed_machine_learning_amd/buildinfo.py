@@ -23,11 +23,13 @@ COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gp
 # they want by name (rsqrtf, __expf) and the reductions rely on a fixed summation order for
 # bit-reproducible training, which reassociation would be free to break.
 # -munsafe-fp-atomics (hardware float atomic add instead of a compare-and-swap loop) only
-# where float atomics exist: the slab-less mode of the weight-gradient kernel and the
-# stand-alone linear / loss kernels, none of which runs in the training step.
+# where float atomics exist: the slab-less mode of the weight-gradient kernel, the stand-alone
+# linear / loss kernels (neither runs in the training step), and the fp32 convolution's
+# two-way tap split (two addends onto zero: order-independent).
 FILE_FLAGS = {
     "conv_wgrad.hip": ["-munsafe-fp-atomics"],
     "optim_loss.hip": ["-munsafe-fp-atomics"],
+    "conv_f32.hip": ["-munsafe-fp-atomics"],
 }
 
 

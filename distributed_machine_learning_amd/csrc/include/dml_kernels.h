@@ -320,7 +320,8 @@ void nchw_to_nhwc4(const float* x, float* out, int batch, hipStream_t stream);
 void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bias,
                        const float* mask, ConvShape s, ConvEpilogue epi, hipStream_t stream,
                        int force_tile = 0 /* tuning: 128 or 64 */,
-                       int force_pm = -1 /* tuning: position-major tiles off / on */);
+                       int force_pm = -1 /* tuning: position-major tiles off / on */,
+                       int force_split = -1 /* tuning: two-way tap split off / on (-1: by grid size) */);
 // wd[cin][8 - tap][cout] = wf[cout][tap][cin]
 void repack_dgrad_weights_f32(const float* wf, float* wd, int cout, int cin, hipStream_t stream);
 // dw[cout][9][cin] = sum_p dy[p][cout] * x[p (+) tap][cin].  The pixel range is split over

@@ -55,6 +55,12 @@ struct IgemmParams {
     const float* bias;
     const float* mask;
     int M, N, cin, hw, log_hw, batch;
+    // position-major only: 2 = the taps of a position are divided between blockIdx.y = 0 / 1 and
+    // the two partial tiles meet in y (zeroed by the launcher) through float atomics.  With
+    // exactly two addends onto zero the result does not depend on which arrives first
+    // (0 + a = a exactly, a + b = b + a), so the kernel stays bit-reproducible; bias and ReLU mask
+    // distribute over the two parts, a ReLU would not (EPI_BIAS_RELU is never split).
+    int tap_splits;
 };
 
 // (waves_per_eu: without the cap hipcc aims for 7 waves per SIMD on the 64 x 64 variant and
@@ -93,7 +99,17 @@ void conv3x3_igemm_f32_kernel(IgemmParams p) {
                 ++ntaps;
             }
         }
+        if (p.tap_splits == 2) {
+            const int half = ntaps >> 1;
+            if (blockIdx.y == 0) {
+                ntaps = half;
+            } else {
+                taps >>= 4 * half;
+                ntaps -= half;
+            }
+        }
     }
+    const bool split = PM && p.tap_splits == 2;
 
     // the rows this thread stages are the same for every chunk
     int a_h[LA], a_w[LA];
@@ -207,7 +223,8 @@ void conv3x3_igemm_f32_kernel(IgemmParams p) {
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const int n = n0 + wn * 32 * NT + b * 32 + r;
-        const float bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) ? p.bias[n] : 0.f;
+        const float bias =
+            ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && !(split && blockIdx.y != 0)) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -218,7 +235,10 @@ void conv3x3_igemm_f32_kernel(IgemmParams p) {
                 float v = acc[a][b][g] + bias;
                 if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
                 if (EPI == EPI_MASK) v = p.mask[at] > 0.f ? v : 0.f;
-                if (ok) p.y[at] = v;
+                if (ok) {
+                    if (split) atomicAdd(p.y + at, v);
+                    else p.y[at] = v;
+                }
             }
         }
     }
@@ -527,22 +547,23 @@ void check_shape(const ConvShape& s, const char* who) {
 
 namespace {
 template <int MT, int NT, bool PM>
-void launch_igemm(const IgemmParams& p, ConvEpilogue epi, unsigned blocks, hipStream_t stream) {
+void launch_igemm(const IgemmParams& p, ConvEpilogue epi, unsigned nblocks, hipStream_t stream) {
+    const dim3 blocks(nblocks, PM ? p.tap_splits : 1);
     switch (epi) {
         case EPI_NONE:
-            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_NONE>), dim3(blocks),
+            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_NONE>), blocks,
                                dim3(256), 0, stream, p);
             break;
         case EPI_BIAS:
-            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_BIAS>), dim3(blocks),
+            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_BIAS>), blocks,
                                dim3(256), 0, stream, p);
             break;
         case EPI_BIAS_RELU:
-            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_BIAS_RELU>), dim3(blocks),
+            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_BIAS_RELU>), blocks,
                                dim3(256), 0, stream, p);
             break;
         case EPI_MASK:
-            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_MASK>), dim3(blocks),
+            hipLaunchKernelGGL((conv3x3_igemm_f32_kernel<MT, NT, PM, EPI_MASK>), blocks,
                                dim3(256), 0, stream, p);
             break;
     }
@@ -551,7 +572,7 @@ void launch_igemm(const IgemmParams& p, ConvEpilogue epi, unsigned blocks, hipSt
 
 void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bias,
                        const float* mask, ConvShape s, ConvEpilogue epi, hipStream_t stream,
-                       int force_tile, int force_pm) {
+                       int force_tile, int force_pm, int force_split) {
     check_shape(s, "conv3x3_igemm_f32");
     if (!x || !w || !y) throw std::invalid_argument("conv3x3_igemm_f32: null tensor");
     if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias)
@@ -582,6 +603,14 @@ void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bi
         throw std::invalid_argument("conv3x3_igemm_f32: tile must be 64 or 128");
     }
     const unsigned blocks = (unsigned)blocks_for(big ? 128 : 64);
+    // Position-major tiles on a map too small to give every CU a block (2x2 at batch 256: 128
+    // blocks): the taps of a position go to two blocks, see IgemmParams::tap_splits.
+    p.tap_splits = 1;
+    if (pm && epi != EPI_BIAS_RELU && blocks < 256 && force_split != 0) p.tap_splits = 2;
+    if (force_split == 1 && pm && epi != EPI_BIAS_RELU) p.tap_splits = 2;
+    if (p.tap_splits == 2)
+        if (hipMemsetAsync(y, 0, (size_t)p.M * p.N * sizeof(float), stream) != hipSuccess)
+            throw std::runtime_error("conv3x3_igemm_f32: hipMemsetAsync failed");
     if (big && pm) launch_igemm<2, 2, true>(p, epi, blocks, stream);
     else if (big) launch_igemm<2, 2, false>(p, epi, blocks, stream);
     else if (pm) launch_igemm<1, 1, true>(p, epi, blocks, stream);

@@ -560,7 +560,7 @@ def fill_uniform_(t: torch.Tensor, seed: int, scale: float = 1.0) -> torch.Tenso
 F32 = torch.float32
 
 
-def conv3x3_fwd_f32(x, wf, bias=None, relu=True, tile=0, pm=-1):
+def conv3x3_fwd_f32(x, wf, bias=None, relu=True, tile=0, pm=-1, split=-1):
     _req(x, F32, "x", 4)
     _req(wf, F32, "wf", 4)
     b, h, w, cin = x.shape
@@ -572,7 +572,7 @@ def conv3x3_fwd_f32(x, wf, bias=None, relu=True, tile=0, pm=-1):
     y = torch.empty(b, h, w, cout, dtype=F32, device=x.device)
     epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
     lib().conv3x3_igemm_f32(x.data_ptr(), wf.data_ptr(), y.data_ptr(), _ptr(bias), 0, b, h, cin, cout,
-                            epi, _stream(), tile, pm)
+                            epi, _stream(), tile, pm, split)
     return y
 
 
@@ -584,7 +584,7 @@ def repack_dgrad_f32(wf):
     return wd
 
 
-def conv3x3_dgrad_f32(dy, wd, relu_mask=None, tile=0, pm=-1):
+def conv3x3_dgrad_f32(dy, wd, relu_mask=None, tile=0, pm=-1, split=-1):
     _req(dy, F32, "dy", 4)
     _req(wd, F32, "wd", 4)
     b, h, w, cout = dy.shape
@@ -597,7 +597,8 @@ def conv3x3_dgrad_f32(dy, wd, relu_mask=None, tile=0, pm=-1):
         if relu_mask.shape != dx.shape:
             raise ValueError("conv3x3_dgrad_f32: mask shape")
     lib().conv3x3_igemm_f32(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0, _ptr(relu_mask), b, h, cout,
-                            cin, EPI_MASK if relu_mask is not None else EPI_NONE, _stream(), tile, pm)
+                            cin, EPI_MASK if relu_mask is not None else EPI_NONE, _stream(), tile, pm,
+                            split)
     return dx
 
 

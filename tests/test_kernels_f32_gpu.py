@@ -57,6 +57,11 @@ def test_conv3x3_fwd_f32(batch, cin, cout, hw):
                 continue
             got = n.conv3x3_fwd_f32(x, w, b, relu=False, tile=tile, pm=pm)
             check(f"fwd tile{tile} pm{pm}", nchw(got), ref)
+            if pm:      # the taps of a position divided between two blocks (two-addend atomics)
+                two = n.conv3x3_fwd_f32(x, w, b, relu=False, tile=tile, pm=1, split=1)
+                check(f"fwd tile{tile} pm split", nchw(two), ref)
+                assert torch.equal(two, n.conv3x3_fwd_f32(x, w, b, relu=False, tile=tile, pm=1,
+                                                          split=1))
 
 
 @pytest.mark.parametrize("batch", BATCHES)
@@ -72,6 +77,11 @@ def test_conv3x3_dgrad_f32(batch, cin, cout, hw):
     for pm in (0, 1):
         got = n.conv3x3_dgrad_f32(dy, wd, relu_mask=mask, pm=pm)
         check(f"dgrad+mask pm{pm}", nchw(got), ref * (nchw(mask) > 0))
+    if hw >= 2:
+        for m in (None, mask):
+            two = n.conv3x3_dgrad_f32(dy, wd, relu_mask=m, pm=1, split=1)
+            check("dgrad pm split", nchw(two), ref if m is None else ref * (nchw(mask) > 0))
+            assert torch.equal(two, n.conv3x3_dgrad_f32(dy, wd, relu_mask=m, pm=1, split=1))
 
 
 @pytest.mark.parametrize("batch", BATCHES)
