@@ -593,7 +593,10 @@ void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bi
         const long mt = pm ? (long)s.hw * s.hw * ((s.batch + tile - 1) / tile) : (p.M + tile - 1) / tile;
         return mt * (p.N / tile);
     };
-    bool big = p.N % 128 == 0 && blocks_for(128) >= 256 && (!pm || s.batch >= 128);
+    // (measured at batch 256, tools/bench_conv_f32.py: on the position-major layers 64 x 64 tiles
+    // win by 8-13 % even where 128 x 128 tiles would still cover the chip - 199 against 224 us at
+    // 256 -> 256 @ 8x8 - and on the 16x16 layer the two are equal)
+    bool big = p.N % 128 == 0 && !pm && blocks_for(128) >= 512;
     if (force_tile == 128) {
         if (p.N % 128) throw std::invalid_argument("conv3x3_igemm_f32: 128 tiles need cout % 128 == 0");
         big = true;
@@ -605,8 +608,11 @@ void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bi
     const unsigned blocks = (unsigned)blocks_for(big ? 128 : 64);
     // Position-major tiles on a map too small to give every CU a block (2x2 at batch 256: 128
     // blocks): the taps of a position go to two blocks, see IgemmParams::tap_splits.
+    // Also worth it on the 4x4 maps whose grid does cover the chip (512 -> 512 @ 4x4: 183 against
+    // 203 us forward, 178 against 202 us backward-data); on 8x8 it loses 3-5 %.
     p.tap_splits = 1;
-    if (pm && epi != EPI_BIAS_RELU && blocks < 256 && force_split != 0) p.tap_splits = 2;
+    if (pm && epi != EPI_BIAS_RELU && (blocks < 256 || s.hw <= 4) && force_split != 0)
+        p.tap_splits = 2;
     if (force_split == 1 && pm && epi != EPI_BIAS_RELU) p.tap_splits = 2;
     if (p.tap_splits == 2)
         if (hipMemsetAsync(y, 0, (size_t)p.M * p.N * sizeof(float), stream) != hipSuccess)
@@ -632,14 +638,18 @@ WgradPlan plan_wgrad(const ConvShape& s, int force_splits, int force_pm) {
     pl.wide = s.cin % 128 == 0;
     if (s.cout % 128) throw std::invalid_argument("conv3x3_wgrad_f32: cout must be a multiple of 128");
     pl.tiles = (s.cout / 128) * (s.cin / (pl.wide ? 128 : 64));
-    pl.pm = s.hw <= 8 && s.hw >= 2 && s.batch >= kBK;
+    // (position-major chunks also pay at 16x16: 122 against 154 us at 64 -> 128, batch 256)
+    pl.pm = s.hw <= 16 && s.hw >= 2 && s.batch >= kBK;
     if (force_pm == 0) pl.pm = false;
     else if (force_pm == 1) pl.pm = s.hw >= 2;
     const int npix = s.hw * s.hw;
     const int chunks = pl.pm ? npix * ((s.batch + kBK - 1) / kBK) : (s.batch * npix + kBK - 1) / kBK;
     pl.total_chunks = chunks;
-    // about two blocks per CU, at least four chunks of pixels per block
-    int splits = force_splits > 0 ? force_splits : (512 + pl.tiles * 9 - 1) / (pl.tiles * 9);
+    // about two blocks per CU, at least four chunks of pixels per block; three times as many on
+    // the 4x4 maps, where position-major blocks skip most of their chunks (512 -> 512 @ 4x4,
+    // batch 256: 174 us with 12 splits against 217 us with 4)
+    const int target = pl.pm && s.hw <= 4 ? 1536 : 512;
+    int splits = force_splits > 0 ? force_splits : (target + pl.tiles * 9 - 1) / (pl.tiles * 9);
     const int max_splits = chunks / 4 > 0 ? chunks / 4 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
