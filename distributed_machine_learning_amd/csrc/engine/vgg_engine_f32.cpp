@@ -260,8 +260,10 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
                         grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream);
         // g is complete: from here the weight gradient (side stream when overlapping) and the
         // input gradient (main stream) are independent.  The main chain is enqueued first.
+        // (the first layer's weight gradient stays on the main stream: by then the main chain has
+        // nothing else left and the side stream still has the second layer's to finish)
         hipStream_t wstream = stream;
-        if (overlap_) {
+        if (overlap_ && i > 0) {
             check_hip(hipEventRecord(grad_ready_[i], stream), "hipEventRecord(grad ready)");
             wstream = side_;
         }
@@ -272,7 +274,7 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
                               fold ? arena_ + buf_[i - 1].out_off : nullptr,
                               {batch, c.hw, c.cout, c.cin}, fold ? EPI_MASK : EPI_NONE, stream);
         }
-        if (overlap_)
+        if (overlap_ && i > 0)
             check_hip(hipStreamWaitEvent(side_, grad_ready_[i], 0), "hipStreamWaitEvent(grad ready)");
         if (i == 0) {
             // Conv bias gradient under BatchNorm: exactly zero in exact arithmetic (the
@@ -296,11 +298,19 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
                 sums_.splits[j] = splits;
             }
         }
+        // The side stream has time to spare (it idles through forward): its slab sums follow
+        // each weight gradient at once instead of piling up behind the last one.
+        if (overlap_ && i > 0) flush_sums(side_);
         // a bucket leaves from the stream that completed it (the BatchNorm gradients it may hold
-        // were written on the main stream before grad_ready_[i])
+        // were written on the main stream before grad_ready_[i]); the last one only after the side
+        // stream's share of it is complete
+        if (overlap_ && i == 0 && reducer_ && !buckets_by_layer_[0].empty()) {
+            check_hip(hipEventRecord(side_done_, side_), "hipEventRecord(side done)");
+            check_hip(hipStreamWaitEvent(stream, side_done_, 0), "hipStreamWaitEvent(side done)");
+        }
         fire_buckets(i, wstream);
     }
-    flush_sums(overlap_ ? side_ : stream);
+    flush_sums(stream);
     if (overlap_) {
         check_hip(hipEventRecord(side_done_, side_), "hipEventRecord(side done)");
         check_hip(hipStreamWaitEvent(stream, side_done_, 0), "hipStreamWaitEvent(side done)");
