@@ -143,7 +143,7 @@ void conv3x3_igemm_f32_kernel(IgemmParams p) {
     // Staging registers of the chunk after the one being multiplied.  Loads are branch-free
     // (a row outside the map or the tensor reads a safe address and is zeroed) and issued
     // unconditionally - the last iteration re-loads the last chunk and nobody reads it.
-    float4 ra[LA], rb[LB];
+    f32x4 ra[LA], rb[LB];
     int ld_tap = 0, ld_chunk = 0;           // position of the next chunk to load
 #define DML_F32_FETCH()                                                                        \
     {                                                                                          \
@@ -155,33 +155,33 @@ void conv3x3_igemm_f32_kernel(IgemmParams p) {
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                       \
             const bool ok = a_ok[i] && (PM || ((unsigned)(a_h[i] + dh) < (unsigned)hw &&       \
                                                (unsigned)(a_w[i] + dw) < (unsigned)hw));       \
-            const float4 v = *(const float4*)(ok ? p.x + a_base[i] + shift : p.x);             \
-            ra[i] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};                                       \
+            const f32x4 v = *(const f32x4*)(ok ? p.x + a_base[i] + shift : p.x);               \
+            ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};                                        \
         }                                                                                      \
         _Pragma("unroll") for (int i = 0; i < LB; ++i)                                         \
-            rb[i] = *(const float4*)(p.w + b_base[i] + (long)tap * cin + c0);                  \
+            rb[i] = *(const f32x4*)(p.w + b_base[i] + (long)tap * cin + c0);                   \
         if (++ld_chunk == chunks) { ld_chunk = 0; ++ld_tap; }                                  \
     }
 #define DML_F32_STASH(buf)                                                                     \
     {                                                                                          \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                       \
             const int idx = tid + 256 * i, row = idx >> 3, slot = (idx & 7) ^ (row & 7);       \
-            *(float4*)(&As[buf][row * kBK + slot * 4]) = ra[i];                                \
+            *(f32x4*)(&As[buf][row * kBK + slot * 4]) = ra[i];                                 \
         }                                                                                      \
         _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                       \
             const int idx = tid + 256 * i, row = idx >> 3, slot = (idx & 7) ^ (row & 7);       \
-            *(float4*)(&Bs[buf][row * kBK + slot * 4]) = rb[i];                                \
+            *(f32x4*)(&Bs[buf][row * kBK + slot * 4]) = rb[i];                                 \
         }                                                                                      \
     }
 #define DML_F32_FRAGS(buf, q, FA, FB)                                                          \
     {                                                                                          \
         _Pragma("unroll") for (int a = 0; a < MT; ++a) {                                       \
             const int row = wm * 32 * MT + a * 32 + r;                                         \
-            FA[a] = *(const float4*)(&As[buf][row * kBK + (((2 * (q) + h) ^ (row & 7)) * 4)]); \
+            FA[a] = *(const f32x4*)(&As[buf][row * kBK + (((2 * (q) + h) ^ (row & 7)) * 4)]);  \
         }                                                                                      \
         _Pragma("unroll") for (int b = 0; b < NT; ++b) {                                       \
             const int row = wn * 32 * NT + b * 32 + r;                                         \
-            FB[b] = *(const float4*)(&Bs[buf][row * kBK + (((2 * (q) + h) ^ (row & 7)) * 4)]); \
+            FB[b] = *(const f32x4*)(&Bs[buf][row * kBK + (((2 * (q) + h) ^ (row & 7)) * 4)]);  \
         }                                                                                      \
     }
 
@@ -195,7 +195,7 @@ void conv3x3_igemm_f32_kernel(IgemmParams p) {
         // barriers pin that order: left alone, hipcc sinks the global loads to the end of the
         // chunk and reads each fragment right before its first use, exposing both latencies
         // on every group (one wave per SIMD has nothing else to run meanwhile).
-        float4 fa[2][MT], fb[2][NT];
+        f32x4 fa[2][MT], fb[2][NT];
         DML_F32_FRAGS(buf, 0, fa[0], fb[0]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -208,8 +208,7 @@ void conv3x3_igemm_f32_kernel(IgemmParams p) {
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
                     for (int b = 0; b < NT; ++b)
-                        acc[a][b] = mfma32(((const float*)&fa[q & 1][a])[t],
-                                           ((const float*)&fb[q & 1][b])[t], acc[a][b]);
+                        acc[a][b] = mfma32(fa[q & 1][a][t], fb[q & 1][b][t], acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
         }
         DML_F32_STASH(buf ^ 1);
