@@ -59,6 +59,11 @@ VggEngineF32::VggEngineF32(const std::vector<int>& widths, int max_batch, bool b
         b.pool_off = a;
         if (c.pool_after) a = align_up(a + act / 4);
         b.gout_off = a; a = align_up(a + act);
+        // (position-major backward-data tiles, the ones that may split, exist up to 8x8 maps)
+        if (i + 1 < lay_.convs.size() && (bn_ || c.pool_after) && lay_.convs[i + 1].hw <= 8) {
+            const ParamLayout::Conv& nx = lay_.convs[i + 1];
+            b.gin_off = a; a = align_up(a + B * nx.hw * nx.hw * nx.cin);
+        }
         buf_.push_back(b);
     }
     ta_off_ = a; a = align_up(a + max_act);
@@ -98,6 +103,8 @@ VggEngineF32::~VggEngineF32() {
     if (side_done_) (void)hipEventDestroy(side_done_);
     if (updated_) (void)hipEventDestroy(updated_);
     if (repack_done_) (void)hipEventDestroy(repack_done_);
+    if (fwd_begin_) (void)hipEventDestroy(fwd_begin_);
+    if (cleared_) (void)hipEventDestroy(cleared_);
     if (side_) (void)hipStreamDestroy(side_);
 }
 
@@ -113,6 +120,8 @@ void VggEngineF32::set_wgrad_overlap(bool on, hipStream_t compute_stream) {
         check_hip(hipEventCreateWithFlags(&side_done_, hipEventDisableTiming), "hipEventCreate");
         check_hip(hipEventCreateWithFlags(&updated_, hipEventDisableTiming), "hipEventCreate");
         check_hip(hipEventCreateWithFlags(&repack_done_, hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&fwd_begin_, hipEventDisableTiming), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&cleared_, hipEventDisableTiming), "hipEventCreate");
     }
     overlap_ = on;
 }
@@ -151,6 +160,57 @@ void VggEngineF32::join_repack(hipStream_t stream) {
     repack_pending_ = false;
 }
 
+// where the gradient arriving at a layer is written: straight into the layer's own buffer when it
+// already is dL/d(conv output) (no BatchNorm, no pool: the producer masks with the layer's ReLU
+// output), else a transit buffer
+float* VggEngineF32::arriving(int layer) const {
+    if (direct(layer)) return arena_ + buf_[layer].gout_off;
+    return arena_ + (buf_[layer].gin_off != kNone ? buf_[layer].gin_off : ta_off_);
+}
+
+void VggEngineF32::clear_split_outputs(int batch, bool training, hipStream_t stream) {
+    const int nconv = (int)lay_.convs.size();
+    fwd_cleared_.assign(nconv, 0);
+    bwd_cleared_.assign(nconv, 0);
+    ZeroJobs jobs;
+    for (int i = 1; i < nconv; ++i) {
+        const ParamLayout::Conv& c = lay_.convs[i];
+        const size_t pixels = (size_t)batch * c.hw * c.hw;
+        if (bn_ && jobs.n < ZeroJobs::kMax &&
+            conv3x3_igemm_f32_tap_splits({batch, c.hw, c.cin, c.cout}, EPI_BIAS) == 2) {
+            jobs.ptr[jobs.n] = arena_ + buf_[i].pre_off;
+            jobs.count[jobs.n++] = pixels * c.cout;
+            fwd_cleared_[i] = 1;
+        }
+        // (the shared transit buffer carries other layers' gradients in between: not cleared ahead)
+        const bool own = direct(i - 1) || buf_[i - 1].gin_off != kNone;
+        if (training && own && jobs.n < ZeroJobs::kMax &&
+            conv3x3_igemm_f32_tap_splits({batch, c.hw, c.cout, c.cin},
+                                         direct(i - 1) ? EPI_MASK : EPI_NONE) == 2) {
+            jobs.ptr[jobs.n] = arriving(i - 1);
+            jobs.count[jobs.n++] = pixels * c.cin;
+            bwd_cleared_[i] = 1;
+        }
+    }
+    if (jobs.n == 0) return;
+    if (overlap_) {
+        // the side stream idles through forward; the first split convolution is far down the net
+        check_hip(hipEventRecord(fwd_begin_, stream), "hipEventRecord(forward begin)");
+        check_hip(hipStreamWaitEvent(side_, fwd_begin_, 0), "hipStreamWaitEvent(forward begin)");
+        zero_buffers(jobs, side_);
+        check_hip(hipEventRecord(cleared_, side_), "hipEventRecord(cleared)");
+        clear_pending_ = true;
+    } else {
+        zero_buffers(jobs, stream);
+    }
+}
+
+void VggEngineF32::join_clear(hipStream_t stream) {
+    if (!clear_pending_) return;
+    check_hip(hipStreamWaitEvent(stream, cleared_, 0), "hipStreamWaitEvent(cleared)");
+    clear_pending_ = false;
+}
+
 void VggEngineF32::refresh_weights(hipStream_t stream) {
     if (!params_) throw std::logic_error("VggEngineF32: bind() first");
     join_repack(stream);        // (a repack of the previous update may still run on the side stream)
@@ -182,15 +242,18 @@ void VggEngineF32::forward(const float* x, int batch, bool training, hipStream_t
     if (batch <= 0 || batch > max_batch_) throw std::invalid_argument("VggEngineF32: bad batch size");
     TraceRange range(training ? "forward" : "forward(eval)");
     const float* in = x;
+    clear_split_outputs(batch, training, stream);
     for (size_t i = 0; i < lay_.convs.size(); ++i) {
         const ParamLayout::Conv& c = lay_.convs[i];
         const Buffers& b = buf_[i];
         float* dst = arena_ + (bn_ ? b.pre_off : b.out_off);
+        if (fwd_cleared_[i]) join_clear(stream);
         if (i == 0)
             conv1_fprop_f32(in, params_ + c.w_off, params_ + c.b_off, dst, batch, !bn_, stream);
         else
             conv3x3_igemm_f32(in, params_ + c.w_off, dst, params_ + c.b_off, nullptr,
-                              {batch, c.hw, c.cin, c.cout}, bn_ ? EPI_BIAS : EPI_BIAS_RELU, stream);
+                              {batch, c.hw, c.cin, c.cout}, bn_ ? EPI_BIAS : EPI_BIAS_RELU, stream,
+                              0, -1, -1, fwd_cleared_[i] != 0);
         if (bn_) {
             const int rows = batch * c.hw * c.hw;
             if (training)
@@ -221,18 +284,13 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
     // the backward-data weight layouts of the last update were written on the side stream while
     // forward ran (see optimizer_step)
     join_repack(stream);
+    join_clear(stream);
     sums_.n = 0;
-    float* ta = arena_ + ta_off_;
     float* tb = arena_ + tb_off_;
-    // where the gradient arriving at layer i is written: straight into the layer's own buffer
-    // when it already is dL/d(conv output) (no BatchNorm, no pool: the producer masks with the
-    // layer's ReLU output), else the transit buffer
-    auto direct = [&](int i) { return !bn_ && !lay_.convs[i].pool_after; };
-    auto arriving = [&](int i) { return direct(i) ? arena_ + buf_[i].gout_off : ta; };
 
     const ParamLayout::Conv& last = lay_.convs[nconv - 1];
     const float* fc_in = arena_ + (last.pool_after ? buf_[nconv - 1].pool_off : buf_[nconv - 1].out_off);
-    float* fc_dx = direct(nconv - 1) ? tb : ta;
+    float* fc_dx = direct(nconv - 1) ? tb : arriving(nconv - 1);
     fc_train_rows(fc_in, params_ + lay_.fcw_off, params_ + lay_.fcb_off, target, ws_ + logits_off_,
                   fc_dx, ws_ + fc_ws_off_, batch, lay_.fc_in, num_classes_, stream);
     fc_train_grads(fc_in, ws_ + fc_ws_off_, ws_ + loss_off_, nullptr, grads_ + lay_.fcw_off,
@@ -272,7 +330,8 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
             const bool fold = direct(i - 1);
             conv3x3_igemm_f32(g, arena_ + b.wd_off, arriving(i - 1), nullptr,
                               fold ? arena_ + buf_[i - 1].out_off : nullptr,
-                              {batch, c.hw, c.cout, c.cin}, fold ? EPI_MASK : EPI_NONE, stream);
+                              {batch, c.hw, c.cout, c.cin}, fold ? EPI_MASK : EPI_NONE, stream,
+                              0, -1, -1, bwd_cleared_[i] != 0);
         }
         if (overlap_ && i > 0)
             check_hip(hipStreamWaitEvent(side_, grad_ready_[i], 0), "hipStreamWaitEvent(grad ready)");

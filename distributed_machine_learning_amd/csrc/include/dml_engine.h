@@ -256,8 +256,12 @@ class VggEngineF32 {
   private:
     struct Buffers {
         size_t wd_off = 0, pre_off = 0, out_off = 0, pool_off = 0, gout_off = 0;   // arena
+        // arena: a transit buffer of the layer's own for the gradient arriving from the next
+        // layer, where that layer's backward-data kernel may split its taps (kNone: shared one)
+        size_t gin_off = kNone;
         size_t save_off = 0, wslab_off = 0;                                        // workspace
     };
+    static constexpr size_t kNone = ~(size_t)0;
     void backward(const float* x, const int64_t* target, int batch, hipStream_t stream);
     void fire_buckets(int layer, hipStream_t stream);
     void flush_sums(hipStream_t stream);
@@ -281,6 +285,16 @@ class VggEngineF32 {
     hipEvent_t side_done_ = nullptr, updated_ = nullptr, repack_done_ = nullptr;
     bool repack_pending_ = false;           // weight layouts of the last update still on the side stream
     void join_repack(hipStream_t stream);
+    // Outputs of the tap-split convolutions (two blocks per position meet through atomics, so the
+    // output starts at zero): all of a step's are cleared by one launch at the start of forward -
+    // on the side stream when there is one - instead of a memset in front of each convolution.
+    std::vector<char> fwd_cleared_, bwd_cleared_;   // per layer: forward / backward-data output
+    hipEvent_t fwd_begin_ = nullptr, cleared_ = nullptr;
+    bool clear_pending_ = false;
+    void clear_split_outputs(int batch, bool training, hipStream_t stream);
+    void join_clear(hipStream_t stream);
+    float* arriving(int layer) const;
+    bool direct(int layer) const { return !bn_ && !lay_.convs[layer].pool_after; }
 };
 
 void bind_engine(pybind11::module_& m);

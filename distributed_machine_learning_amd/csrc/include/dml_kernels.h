@@ -321,7 +321,19 @@ void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bi
                        const float* mask, ConvShape s, ConvEpilogue epi, hipStream_t stream,
                        int force_tile = 0 /* tuning: 128 or 64 */,
                        int force_pm = -1 /* tuning: position-major tiles off / on */,
-                       int force_split = -1 /* tuning: two-way tap split off / on (-1: by grid size) */);
+                       int force_split = -1 /* tuning: two-way tap split off / on (-1: by grid size) */,
+                       bool pre_zeroed = false /* y is already zero: skip the tap split's memset */);
+// 2 when the default plan divides the taps of a position between two blocks that meet in y through
+// atomics - y must then be zero before the launch (the launcher clears it unless pre_zeroed)
+int conv3x3_igemm_f32_tap_splits(ConvShape s, ConvEpilogue epi);
+// several fp32 buffers cleared in one launch (counts in floats, multiples of 4, 16-byte aligned)
+struct ZeroJobs {
+    static constexpr int kMax = 16;
+    int n = 0;
+    float* ptr[kMax];
+    size_t count[kMax];
+};
+void zero_buffers(const ZeroJobs& jobs, hipStream_t stream);
 // wd[cin][8 - tap][cout] = wf[cout][tap][cin]
 void repack_dgrad_weights_f32(const float* wf, float* wd, int cout, int cin, hipStream_t stream);
 // dw[cout][9][cin] = sum_p dy[p][cout] * x[p (+) tap][cin].  The pixel range is split over

@@ -535,6 +535,13 @@ __global__ __launch_bounds__(256) void repack_dgrad_f32_kernel(const float* __re
     wd[idx] = wf[((size_t)co * 9 + (8 - t)) * cin + ci];
 }
 
+__global__ __launch_bounds__(256) void zero_buffers_kernel(ZeroJobs jobs) {
+    float4* p = (float4*)jobs.ptr[blockIdx.y];
+    const size_t n4 = jobs.count[blockIdx.y] / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        p[i] = float4{0.f, 0.f, 0.f, 0.f};
+}
+
 void check_shape(const ConvShape& s, const char* who) {
     if (s.batch <= 0 || s.hw < 1 || s.hw > 32 || s.cin % 64 || s.cout % 64 || s.cin < 64 ||
         s.cout < 64)
@@ -569,9 +576,30 @@ void launch_igemm(const IgemmParams& p, ConvEpilogue epi, unsigned nblocks, hipS
 }
 }  // namespace
 
+void zero_buffers(const ZeroJobs& jobs, hipStream_t stream) {
+    if (jobs.n <= 0) return;
+    if (jobs.n > ZeroJobs::kMax) throw std::invalid_argument("zero_buffers: too many buffers");
+    for (int j = 0; j < jobs.n; ++j)
+        if (!jobs.ptr[j] || jobs.count[j] % 4 || ((uintptr_t)jobs.ptr[j] & 15))
+            throw std::invalid_argument("zero_buffers: buffers must be 16-byte aligned, counts % 4 == 0");
+    hipLaunchKernelGGL(zero_buffers_kernel, dim3(256, jobs.n), dim3(256), 0, stream, jobs);
+}
+
+namespace {
+// the launch decisions of conv3x3_igemm_f32, shared with conv3x3_igemm_f32_tap_splits
+struct IgemmPlan { bool pm, big; unsigned blocks; int tap_splits; };
+IgemmPlan plan_igemm(const ConvShape& s, ConvEpilogue epi, int force_tile, int force_pm,
+                     int force_split);
+}  // namespace
+
+int conv3x3_igemm_f32_tap_splits(ConvShape s, ConvEpilogue epi) {
+    check_shape(s, "conv3x3_igemm_f32");
+    return plan_igemm(s, epi, 0, -1, -1).tap_splits;
+}
+
 void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bias,
                        const float* mask, ConvShape s, ConvEpilogue epi, hipStream_t stream,
-                       int force_tile, int force_pm, int force_split) {
+                       int force_tile, int force_pm, int force_split, bool pre_zeroed) {
     check_shape(s, "conv3x3_igemm_f32");
     if (!x || !w || !y) throw std::invalid_argument("conv3x3_igemm_f32: null tensor");
     if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias)
@@ -582,45 +610,59 @@ void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bi
     p.x = x; p.w = w; p.y = y; p.bias = bias; p.mask = mask;
     p.M = s.batch * s.hw * s.hw; p.N = s.cout; p.cin = s.cin; p.hw = s.hw;
     p.log_hw = log2_exact(s.hw); p.batch = s.batch;
+    const IgemmPlan pl = plan_igemm(s, epi, force_tile, force_pm, force_split);
+    p.tap_splits = pl.tap_splits;
+    if (pl.tap_splits == 2 && !pre_zeroed)
+        if (hipMemsetAsync(y, 0, (size_t)p.M * p.N * sizeof(float), stream) != hipSuccess)
+            throw std::runtime_error("conv3x3_igemm_f32: hipMemsetAsync failed");
+    if (pl.big && pl.pm) launch_igemm<2, 2, true>(p, epi, pl.blocks, stream);
+    else if (pl.big) launch_igemm<2, 2, false>(p, epi, pl.blocks, stream);
+    else if (pl.pm) launch_igemm<1, 1, true>(p, epi, pl.blocks, stream);
+    else launch_igemm<1, 1, false>(p, epi, pl.blocks, stream);
+}
+
+namespace {
+IgemmPlan plan_igemm(const ConvShape& s, ConvEpilogue epi, int force_tile, int force_pm,
+                     int force_split) {
+    const long M = (long)s.batch * s.hw * s.hw;
+    const int N = s.cout;
     // position-major tiles (padded taps skipped) on the small maps, when a tile of images fills
     bool pm = s.hw <= 8 && s.hw >= 2 && s.batch >= 64;
     if (force_pm == 0) pm = false;
     else if (force_pm == 1) pm = s.hw >= 2;
     else if (force_pm != -1) throw std::invalid_argument("conv3x3_igemm_f32: pm must be -1, 0 or 1");
-    // 128 x 128 tiles where they still give every CU a block, 64 x 64 tiles otherwise
+    // 128 x 128 tiles where they still give every CU two blocks, 64 x 64 tiles otherwise
     auto blocks_for = [&](int tile) {
-        const long mt = pm ? (long)s.hw * s.hw * ((s.batch + tile - 1) / tile) : (p.M + tile - 1) / tile;
-        return mt * (p.N / tile);
+        const long mt = pm ? (long)s.hw * s.hw * ((s.batch + tile - 1) / tile) : (M + tile - 1) / tile;
+        return mt * (N / tile);
     };
     // (measured at batch 256, tools/bench_conv_f32.py: on the position-major layers 64 x 64 tiles
-    // win by 8-13 % even where 128 x 128 tiles would still cover the chip - 199 against 224 us at
-    // 256 -> 256 @ 8x8 - and on the 16x16 layer the two are equal)
-    bool big = p.N % 128 == 0 && !pm && blocks_for(128) >= 512;
+    // win by 8-13 % even where 128 x 128 tiles would still cover the chip, and on the 16x16 layer
+    // 128 x 128 tiles win by 5 %)
+    bool big = N % 128 == 0 && !pm && blocks_for(128) >= 512;
     if (force_tile == 128) {
-        if (p.N % 128) throw std::invalid_argument("conv3x3_igemm_f32: 128 tiles need cout % 128 == 0");
+        if (N % 128) throw std::invalid_argument("conv3x3_igemm_f32: 128 tiles need cout % 128 == 0");
         big = true;
     } else if (force_tile == 64) {
         big = false;
     } else if (force_tile != 0) {
         throw std::invalid_argument("conv3x3_igemm_f32: tile must be 64 or 128");
     }
-    const unsigned blocks = (unsigned)blocks_for(big ? 128 : 64);
+    IgemmPlan pl;
+    pl.pm = pm;
+    pl.big = big;
+    pl.blocks = (unsigned)blocks_for(big ? 128 : 64);
     // Position-major tiles on a map too small to give every CU a block (2x2 at batch 256: 128
-    // blocks): the taps of a position go to two blocks, see IgemmParams::tap_splits.
-    // Also worth it on the 4x4 maps whose grid does cover the chip (512 -> 512 @ 4x4: 183 against
-    // 203 us forward, 178 against 202 us backward-data); on 8x8 it loses 3-5 %.
-    p.tap_splits = 1;
-    if (pm && epi != EPI_BIAS_RELU && (blocks < 256 || s.hw <= 4) && force_split != 0)
-        p.tap_splits = 2;
-    if (force_split == 1 && pm && epi != EPI_BIAS_RELU) p.tap_splits = 2;
-    if (p.tap_splits == 2)
-        if (hipMemsetAsync(y, 0, (size_t)p.M * p.N * sizeof(float), stream) != hipSuccess)
-            throw std::runtime_error("conv3x3_igemm_f32: hipMemsetAsync failed");
-    if (big && pm) launch_igemm<2, 2, true>(p, epi, blocks, stream);
-    else if (big) launch_igemm<2, 2, false>(p, epi, blocks, stream);
-    else if (pm) launch_igemm<1, 1, true>(p, epi, blocks, stream);
-    else launch_igemm<1, 1, false>(p, epi, blocks, stream);
+    // blocks): the taps of a position go to two blocks, see IgemmParams::tap_splits.  Also worth
+    // it on the 4x4 maps whose grid does cover the chip (512 -> 512 @ 4x4: 184 against 206 us
+    // forward, 174 against 197 us backward-data); on 8x8 it loses 3-5 %.
+    pl.tap_splits = 1;
+    if (pm && epi != EPI_BIAS_RELU && (pl.blocks < 256 || s.hw <= 4) && force_split != 0)
+        pl.tap_splits = 2;
+    if (force_split == 1 && pm && epi != EPI_BIAS_RELU) pl.tap_splits = 2;
+    return pl;
 }
+}  // namespace
 
 void repack_dgrad_weights_f32(const float* wf, float* wd, int cout, int cin, hipStream_t stream) {
     if (cout <= 0 || cin <= 0) throw std::invalid_argument("repack_dgrad_weights_f32: bad shape");
