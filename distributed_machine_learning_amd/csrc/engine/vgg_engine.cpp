@@ -330,8 +330,9 @@ void VggEngine::hand_off_wgrads(int batch, bool last) {
     wgrad_queue_.clear();
     // The slab sums follow their weight gradients at once when a bucket may be waiting for them,
     // and under BatchNorm (measured faster); without either, one batched launch at the end of
-    // the side stream's work interferes least with the main chain (0.574 -> 0.567 ms).
-    if (reducer_ || bn_ || last) flush_wgrad_sums(wgrad_stream_);
+    // the side stream's work interferes least with the main chain (0.574 -> 0.567 ms).  (An
+    // optimizer slice that follows this hand-off reads the summed gradients too.)
+    if (reducer_ || bn_ || last || opt_.on) flush_wgrad_sums(wgrad_stream_);
     side_busy_ = true;
 }
 
