@@ -254,6 +254,21 @@ void VggEngineF32::forward(const float* x, int batch, bool training, hipStream_t
             conv3x3_igemm_f32(in, params_ + c.w_off, dst, params_ + c.b_off, nullptr,
                               {batch, c.hw, c.cin, c.cout}, bn_ ? EPI_BIAS : EPI_BIAS_RELU, stream,
                               0, -1, -1, fwd_cleared_[i] != 0);
+        if (bn_ && c.pool_after) {
+            // BatchNorm + ReLU + pool in one pass: only the pooled activation is stored (backward
+            // re-derives the window winners from the conv output)
+            if (training)
+                bn_relu_pool_fwd_train(dst, arena_ + b.pool_off, params_ + c.gamma_off,
+                                       params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off,
+                                       ws_ + b.save_off, ws_ + b.save_off + c.cout,
+                                       ws_ + stats_off_, batch, c.hw, c.cout, 0.1f, 1e-5f, stream);
+            else
+                bn_relu_pool_fwd_eval(dst, arena_ + b.pool_off, params_ + c.gamma_off,
+                                      params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off,
+                                      batch, c.hw, c.cout, 1e-5f, stream);
+            in = arena_ + b.pool_off;
+            continue;
+        }
         if (bn_) {
             const int rows = batch * c.hw * c.hw;
             if (training)
@@ -306,13 +321,16 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
         const int rows = batch * c.hw * c.hw;
         float* g = arena_ + b.gout_off;             // dL/d(conv output)
         float* src = arriving(i);
-        if (c.pool_after) {
+        if (bn_ && c.pool_after)
+            // pool routing, ReLU mask and BatchNorm backward in one reduction and one apply pass
+            bn_relu_pool_bwd(arena_ + b.pre_off, src, g, params_ + c.gamma_off,
+                             params_ + c.beta_off, ws_ + b.save_off, ws_ + b.save_off + c.cout,
+                             grads_ + c.gamma_off, grads_ + c.beta_off, ws_ + stats_off_, batch,
+                             c.hw, c.cout, stream);
+        else if (c.pool_after)
             // without BatchNorm the ReLU mask rides in the pool's routing (out is post-ReLU)
-            float* dst = bn_ ? tb : g;
-            maxpool2x2_bwd(arena_ + b.out_off, src, dst, batch, c.hw, c.cout, !bn_, stream);
-            src = dst;
-        }
-        if (bn_)
+            maxpool2x2_bwd(arena_ + b.out_off, src, g, batch, c.hw, c.cout, true, stream);
+        else if (bn_)
             bn_relu_bwd(arena_ + b.pre_off, src, g, params_ + c.gamma_off, params_ + c.beta_off,
                         ws_ + b.save_off, ws_ + b.save_off + c.cout, grads_ + c.gamma_off,
                         grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream);

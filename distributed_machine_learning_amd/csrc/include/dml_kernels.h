@@ -228,6 +228,17 @@ void bn_relu_pool_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float
                       hipStream_t stream, SplitSlabs dy_slabs = {}, BnPartials sums = {});
 // (`sums`: the dbeta / dgamma partial rows were already produced by the convolution that wrote
 // dy, see BnPoolReduce - the reduction pass is skipped)
+// fp32 activations: the same passes
+void bn_relu_pool_fwd_train(const float* x, float* y, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* save_mean,
+                            float* save_rstd, float* ws, int batch, int hw, int c, float momentum,
+                            float eps, hipStream_t stream);
+void bn_relu_pool_fwd_eval(const float* x, float* y, const float* gamma, const float* beta,
+                           const float* running_mean, const float* running_var, int batch, int hw,
+                           int c, float eps, hipStream_t stream);
+void bn_relu_pool_bwd(const float* x, float* dy, float* dx, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                      float* ws, int batch, int hw, int c, hipStream_t stream);
 
 // ---------------------------------------------------------------- classifier + loss
 // logits[b][n] = sum_k x[b][k] * w[n][k] + bias[n]      (x bf16, w/bias/logits fp32, n <= 16)

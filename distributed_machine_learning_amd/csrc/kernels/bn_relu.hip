@@ -360,7 +360,8 @@ bool bn_relu_bwd_small(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const floa
 
 // (fold + apply in one launch when the reduction left few enough partial rows; defined with its
 // kernel further down)
-bool bn_bwd_fold_apply_plain(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+template <typename T>
+bool bn_bwd_fold_apply_plain(const T* x, const T* dy, T* dx, const float* gamma,
                              const float* beta, const float* save_mean, const float* save_rstd,
                              const float* partials, int nb, float* dgamma, float* dbeta, int rows,
                              int c, hipStream_t stream);
@@ -382,8 +383,8 @@ void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gam
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, uint16_t>), dim3(pl.blocks), dim3(256), 0,
                            stream, x, dy, gamma, beta, save_mean, save_rstd, ws, rows, c,
                            pl.rows_per_block, sl);
-    if (bn_bwd_fold_apply_plain(x, dy, dx, gamma, beta, save_mean, save_rstd, ws, pl.blocks, dgamma,
-                                dbeta, rows, c, stream))
+    if (bn_bwd_fold_apply_plain<uint16_t>(x, dy, dx, gamma, beta, save_mean, save_rstd, ws, pl.blocks,
+                                          dgamma, dbeta, rows, c, stream))
         return;
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
                        (const float*)ws, dgamma, dbeta, pl.blocks, c);
@@ -393,7 +394,7 @@ void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gam
                        (const float*)dgamma, (const float*)dbeta, rows, c, total8);
 }
 
-// fp32 activations: the same three launches (no split slabs, no one-launch variant)
+// fp32 activations: the same launches (no split slabs, no one-launch variant)
 void bn_relu_bwd(const float* x, float* dy, float* dx, const float* gamma, const float* beta,
                  const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                  float* ws, int rows, int c, hipStream_t stream) {
@@ -402,6 +403,9 @@ void bn_relu_bwd(const float* x, float* dy, float* dx, const float* gamma, const
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, float>), dim3(pl.blocks), dim3(256), 0, stream,
                        x, dy, gamma, beta, save_mean, save_rstd, ws, rows, c, pl.rows_per_block,
                        SplitSlabs());
+    if (bn_bwd_fold_apply_plain<float>(x, dy, dx, gamma, beta, save_mean, save_rstd, ws, pl.blocks,
+                                       dgamma, dbeta, rows, c, stream))
+        return;
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
                        (const float*)ws, dgamma, dbeta, pl.blocks, c);
     const size_t total8 = (size_t)rows * (c / 8);
@@ -438,11 +442,25 @@ __device__ __forceinline__ void load_window(const uint16_t* __restrict__ x, size
     const uint4 q3 = *(const uint4*)(p + (size_t)hw * c + c);
     unpack8(q0, v[0]); unpack8(q1, v[1]); unpack8(q2, v[2]); unpack8(q3, v[3]);
 }
+__device__ __forceinline__ void load_window(const float* __restrict__ x, size_t ipix, int cg,
+                                            int c, int hw, float (&v)[4][8]) {
+    const float* p = x + ipix * c + cg * 8;
+    load8(p, v[0]); load8(p + c, v[1]);
+    load8(p + (size_t)hw * c, v[2]); load8(p + (size_t)hw * c + c, v[3]);
+}
+// the four positions of a window written back (backward)
+template <typename T>
+__device__ __forceinline__ void store_window(T* __restrict__ dx, size_t ipix, int col, int c, int hw,
+                                             const float (&o)[4][8]) {
+    T* p = dx + ipix * c + col;
+    store8(p, o[0]); store8(p + c, o[1]);
+    store8(p + (size_t)hw * c, o[2]); store8(p + (size_t)hw * c + c, o[3]);
+}
 
 
-template <bool FROM_VAR>
+template <bool FROM_VAR, typename T>
 __global__ __launch_bounds__(256) void bn_apply_pool_kernel(
-    const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
+    const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean,
     const float* __restrict__ rstd_or_var, int c, float eps, PoolGeom geo, size_t total8) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -471,7 +489,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(
             const float z3 = __builtin_fmaf(v[3][k], sc[k], sh[k]);
             o[k] = fmaxf(fmaxf(fmaxf(z0, z1), fmaxf(z2, z3)), 0.f);
         }
-        *(uint4*)(y + i * 8) = pack8(o);
+        store8(y + i * 8, o);
     }
 }
 
@@ -487,9 +505,9 @@ __device__ __forceinline__ int window_winner(float z0, float z1, float z2, float
     return w;
 }
 
-template <bool SLABS>
+template <bool SLABS, typename T>
 __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(
-    const uint16_t* __restrict__ x, uint16_t* __restrict__ dy,
+    const T* __restrict__ x, T* __restrict__ dy,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ ws,
     int out_rows, int c, int rows_per_block, PoolGeom geo, SplitSlabs sl) {
@@ -528,8 +546,9 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(
         ws, out_rows, c, rows_per_block, red);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
-    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+    const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ dgamma, const float* __restrict__ dbeta, int in_rows, int c,
@@ -557,7 +576,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
         float v[4][8], g[8], o[4][8];
         const size_t ipix = geo.in_pixel(i / geo.c8);
         load_window(x, ipix, cg, c, geo.hw, v);
-        unpack8(*(const uint4*)(dy + i * 8), g);
+        load8(dy + i * 8, g);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             bool live;
@@ -570,11 +589,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
             for (int q = 0; q < 4; ++q)
                 o[q][k] = __builtin_fmaf(-k3[k], v[q][k], (w == q ? gk : 0.f) - k2[k]);
         }
-        uint16_t* p = dx + ipix * c + cg * 8;
-        *(uint4*)(p) = pack8(o[0]);
-        *(uint4*)(p + c) = pack8(o[1]);
-        *(uint4*)(p + (size_t)geo.hw * c) = pack8(o[2]);
-        *(uint4*)(p + (size_t)geo.hw * c + c) = pack8(o[3]);
+        store_window(dx, ipix, cg * 8, c, geo.hw, o);
     }
 }
 
@@ -861,9 +876,9 @@ PoolGeom pool_geom(int batch, int hw, int c, const char* who) {
 // the blocks of the first row chunk store the two gradients, then the tensor is streamed once.
 constexpr int kBwdFoldMaxRows = 256;
 
-template <bool POOL>
+template <bool POOL, typename T>
 __global__ __launch_bounds__(256) void bn_bwd_fold_apply_kernel(
-    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+    const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ partials, int nb, float* __restrict__ dgamma,
@@ -922,7 +937,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fold_apply_kernel(
     }
     for (int r = blockIdx.x * 64 + rl; r < out_rows; r += gridDim.x * 64) {
         float g[8];
-        unpack8(*(const uint4*)(dy + (size_t)r * c + col), g);
+        load8(dy + (size_t)r * c + col, g);
         if constexpr (POOL) {
             float v[4][8], o[4][8];
             const size_t ipix = geo.in_pixel((size_t)r);
@@ -939,20 +954,16 @@ __global__ __launch_bounds__(256) void bn_bwd_fold_apply_kernel(
                 for (int q = 0; q < 4; ++q)
                     o[q][k] = __builtin_fmaf(-k3[k], v[q][k], (w == q ? gk : 0.f) - k2[k]);
             }
-            uint16_t* p = dx + ipix * c + col;
-            *(uint4*)(p) = pack8(o[0]);
-            *(uint4*)(p + c) = pack8(o[1]);
-            *(uint4*)(p + (size_t)geo.hw * c) = pack8(o[2]);
-            *(uint4*)(p + (size_t)geo.hw * c + c) = pack8(o[3]);
+            store_window(dx, ipix, col, c, geo.hw, o);
         } else {
             float v[8], o[8];
-            unpack8(*(const uint4*)(x + (size_t)r * c + col), v);
+            load8(x + (size_t)r * c + col, v);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float gi = (__builtin_fmaf(v[k], ysc[k], ysh[k]) > 0.f) ? g[k] : 0.f;
                 o[k] = k1[k] * gi - k2[k] - k3[k] * v[k];
             }
-            *(uint4*)(dx + (size_t)r * c + col) = pack8(o);
+            store8(dx + (size_t)r * c + col, o);
         }
     }
 }
@@ -963,28 +974,38 @@ bool fold_in_bwd_apply(int nb, int c) {
 }
 }  // namespace
 
-bool bn_bwd_fold_apply_plain(const bf16_raw* x, const bf16_raw* dy, bf16_raw* dx, const float* gamma,
+template <typename T>
+bool bn_bwd_fold_apply_plain(const T* x, const T* dy, T* dx, const float* gamma,
                              const float* beta, const float* save_mean, const float* save_rstd,
                              const float* partials, int nb, float* dgamma, float* dbeta, int rows,
                              int c, hipStream_t stream) {
     if (!fold_in_bwd_apply(nb, c)) return false;
     const PoolGeom none = {c / 8, 0, 0};
-    hipLaunchKernelGGL(bn_bwd_fold_apply_kernel<false>, fold_apply_grid(rows, c), dim3(256), 0, stream,
-                       x, dy, dx, gamma, beta, save_mean, save_rstd, partials, nb, dgamma, dbeta,
-                       rows, c, none, rows);
+    hipLaunchKernelGGL((bn_bwd_fold_apply_kernel<false, T>), fold_apply_grid(rows, c), dim3(256), 0,
+                       stream, x, dy, dx, gamma, beta, save_mean, save_rstd, partials, nb, dgamma,
+                       dbeta, rows, c, none, rows);
     return true;
 }
+template bool bn_bwd_fold_apply_plain<uint16_t>(const uint16_t*, const uint16_t*, uint16_t*,
+                                                const float*, const float*, const float*,
+                                                const float*, const float*, int, float*, float*, int,
+                                                int, hipStream_t);
+template bool bn_bwd_fold_apply_plain<float>(const float*, const float*, float*, const float*,
+                                             const float*, const float*, const float*, const float*,
+                                             int, float*, float*, int, int, hipStream_t);
 
-void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
-                            float* running_mean, float* running_var, float* save_mean,
-                            float* save_rstd, float* ws, int batch, int hw, int c, float momentum,
-                            float eps, hipStream_t stream, BnPartials from) {
+namespace {
+template <typename T>
+void pool_fwd_train_launch(const T* x, T* y, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* save_mean,
+                           float* save_rstd, float* ws, int batch, int hw, int c, float momentum,
+                           float eps, hipStream_t stream, BnPartials from) {
     const int rows = batch * hw * hw;
     check(rows, c, "bn_relu_pool_fwd_train");
     const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_fwd_train");
     const BnPartials part = statistics_partials(x, ws, rows, c, from, stream);
     if (fold_in_apply(part.rows, c)) {
-        hipLaunchKernelGGL((bn_fold_apply_kernel<true, uint16_t>), fold_apply_grid(rows / 4, c),
+        hipLaunchKernelGGL((bn_fold_apply_kernel<true, T>), fold_apply_grid(rows / 4, c),
                            dim3(256), 0, stream, x, y, gamma, beta, part.data, part.rows, part.shift,
                            save_mean, save_rstd, running_mean, running_var, rows, momentum, eps, c,
                            geo, rows / 4);
@@ -993,20 +1014,48 @@ void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, 
     finish_statistics(part, rows, c, save_mean, save_rstd, running_mean, running_var, momentum, eps,
                       stream);
     const size_t total8 = (size_t)(rows / 4) * (c / 8);
-    hipLaunchKernelGGL(bn_apply_pool_kernel<false>, dim3(apply_blocks(total8)), dim3(256), 0,
+    hipLaunchKernelGGL((bn_apply_pool_kernel<false, T>), dim3(apply_blocks(total8)), dim3(256), 0,
                        stream, x, y, gamma, beta, (const float*)save_mean,
                        (const float*)save_rstd, c, eps, geo, total8);
+}
+
+template <typename T>
+void pool_fwd_eval_launch(const T* x, T* y, const float* gamma, const float* beta,
+                          const float* running_mean, const float* running_var, int batch, int hw,
+                          int c, float eps, hipStream_t stream) {
+    const int rows = batch * hw * hw;
+    check(rows, c, "bn_relu_pool_fwd_eval");
+    const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_fwd_eval");
+    const size_t total8 = (size_t)(rows / 4) * (c / 8);
+    hipLaunchKernelGGL((bn_apply_pool_kernel<true, T>), dim3(apply_blocks(total8)), dim3(256), 0,
+                       stream, x, y, gamma, beta, running_mean, running_var, c, eps, geo, total8);
+}
+}  // namespace
+
+void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* save_mean,
+                            float* save_rstd, float* ws, int batch, int hw, int c, float momentum,
+                            float eps, hipStream_t stream, BnPartials from) {
+    pool_fwd_train_launch(x, y, gamma, beta, running_mean, running_var, save_mean, save_rstd, ws,
+                          batch, hw, c, momentum, eps, stream, from);
+}
+void bn_relu_pool_fwd_train(const float* x, float* y, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* save_mean,
+                            float* save_rstd, float* ws, int batch, int hw, int c, float momentum,
+                            float eps, hipStream_t stream) {
+    pool_fwd_train_launch(x, y, gamma, beta, running_mean, running_var, save_mean, save_rstd, ws,
+                          batch, hw, c, momentum, eps, stream, BnPartials());
 }
 
 void bn_relu_pool_fwd_eval(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                            const float* running_mean, const float* running_var, int batch, int hw,
                            int c, float eps, hipStream_t stream) {
-    const int rows = batch * hw * hw;
-    check(rows, c, "bn_relu_pool_fwd_eval");
-    const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_fwd_eval");
-    const size_t total8 = (size_t)(rows / 4) * (c / 8);
-    hipLaunchKernelGGL(bn_apply_pool_kernel<true>, dim3(apply_blocks(total8)), dim3(256), 0, stream,
-                       x, y, gamma, beta, running_mean, running_var, c, eps, geo, total8);
+    pool_fwd_eval_launch(x, y, gamma, beta, running_mean, running_var, batch, hw, c, eps, stream);
+}
+void bn_relu_pool_fwd_eval(const float* x, float* y, const float* gamma, const float* beta,
+                           const float* running_mean, const float* running_var, int batch, int hw,
+                           int c, float eps, hipStream_t stream) {
+    pool_fwd_eval_launch(x, y, gamma, beta, running_mean, running_var, batch, hw, c, eps, stream);
 }
 
 void bn_relu_pool_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
@@ -1032,27 +1081,56 @@ void bn_relu_pool_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float
         nb = sums.rows;
         partials = sums.data;
     } else if (sl.splits > 0) {
-        hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<true>, dim3(pl.blocks), dim3(256), 0, stream, x,
-                           dy, gamma, beta, save_mean, save_rstd, ws, out_rows, c,
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<true, uint16_t>), dim3(pl.blocks), dim3(256), 0,
+                           stream, x, dy, gamma, beta, save_mean, save_rstd, ws, out_rows, c,
                            pl.rows_per_block, geo, sl);
     } else {
-        hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<false>, dim3(pl.blocks), dim3(256), 0, stream,
-                           x, dy, gamma, beta, save_mean, save_rstd, ws, out_rows, c,
+        hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<false, uint16_t>), dim3(pl.blocks), dim3(256), 0,
+                           stream, x, dy, gamma, beta, save_mean, save_rstd, ws, out_rows, c,
                            pl.rows_per_block, geo, sl);
     }
     if (dx && fold_in_bwd_apply(nb, c)) {
-        hipLaunchKernelGGL(bn_bwd_fold_apply_kernel<true>, fold_apply_grid(out_rows, c), dim3(256), 0,
-                           stream, x, (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd,
-                           partials, nb, dgamma, dbeta, rows, c, geo, out_rows);
+        hipLaunchKernelGGL((bn_bwd_fold_apply_kernel<true, uint16_t>), fold_apply_grid(out_rows, c),
+                           dim3(256), 0, stream, x, (const uint16_t*)dy, dx, gamma, beta, save_mean,
+                           save_rstd, partials, nb, dgamma, dbeta, rows, c, geo, out_rows);
         return;
     }
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream, partials,
                        dgamma, dbeta, nb, c);
     if (!dx) return;        // the caller's next kernel produces dx on the fly (conv1_wgrad_bn_pool)
     const size_t total8 = (size_t)out_rows * (c / 8);
-    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(apply_blocks(total8)), dim3(256), 0, stream,
-                       x, (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd, (const float*)dgamma,
-                       (const float*)dbeta, rows, c, geo, total8);
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<uint16_t>, dim3(apply_blocks(total8)), dim3(256), 0,
+                       stream, x, (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd,
+                       (const float*)dgamma, (const float*)dbeta, rows, c, geo, total8);
+}
+
+// fp32 activations: partial sums, then fold + apply (or fold and apply) - no split slabs, no
+// one-launch variant, no sums from a producer's epilogue
+void bn_relu_pool_bwd(const float* x, float* dy, float* dx, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                      float* ws, int batch, int hw, int c, hipStream_t stream) {
+    const int rows = batch * hw * hw;
+    check(rows, c, "bn_relu_pool_bwd");
+    if (!dx) throw std::invalid_argument("bn_relu_pool_bwd: dx missing");
+    const PoolGeom geo = pool_geom(batch, hw, c, "bn_relu_pool_bwd");
+    const int out_rows = rows / 4;
+    const ColReducePlan pl = plan_col_reduce(out_rows, c);
+    hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<false, float>), dim3(pl.blocks), dim3(256), 0,
+                       stream, x, dy, gamma, beta, save_mean, save_rstd, ws, out_rows, c,
+                       pl.rows_per_block, geo, SplitSlabs());
+    if (fold_in_bwd_apply(pl.blocks, c)) {
+        hipLaunchKernelGGL((bn_bwd_fold_apply_kernel<true, float>), fold_apply_grid(out_rows, c),
+                           dim3(256), 0, stream, x, (const float*)dy, dx, gamma, beta, save_mean,
+                           save_rstd, (const float*)ws, pl.blocks, dgamma, dbeta, rows, c, geo,
+                           out_rows);
+        return;
+    }
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
+                       (const float*)ws, dgamma, dbeta, pl.blocks, c);
+    const size_t total8 = (size_t)out_rows * (c / 8);
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<float>, dim3(apply_blocks(total8)), dim3(256), 0,
+                       stream, x, (const float*)dy, dx, gamma, beta, save_mean, save_rstd,
+                       (const float*)dgamma, (const float*)dbeta, rows, c, geo, total8);
 }
 
 }  // namespace dml

@@ -700,6 +700,54 @@ def bn_relu_bwd_f32(x, dy, gamma, beta, save_mean, save_rstd):
     return dx, dgamma, dbeta
 
 
+def bn_relu_pool_fwd_train_f32(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1,
+                               eps=1e-5):
+    """BatchNorm + ReLU + 2x2 max-pool of an fp32 NHWC conv output in one pass: returns the pooled
+    activation and the batch statistics backward needs."""
+    _req(x, F32, "x", 4)
+    b, h, w, c = x.shape
+    if h != w or h % 2:
+        raise ValueError("bn_relu_pool: square even inputs only")
+    y = torch.empty(b, h // 2, w // 2, c, dtype=F32, device=x.device)
+    mean = torch.empty(c, dtype=F32, device=x.device)
+    rstd = torch.empty(c, dtype=F32, device=x.device)
+    lib().bn_relu_pool_fwd_train_f32(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                     _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
+                                     rstd.data_ptr(), _reduce_ws(x.device).data_ptr(), b, h, c,
+                                     momentum, eps, _stream())
+    return y, mean, rstd
+
+
+def bn_relu_pool_fwd_eval_f32(x, gamma, beta, running_mean, running_var, eps=1e-5):
+    _req(x, F32, "x", 4)
+    b, h, w, c = x.shape
+    if h != w or h % 2:
+        raise ValueError("bn_relu_pool: square even inputs only")
+    y = torch.empty(b, h // 2, w // 2, c, dtype=F32, device=x.device)
+    lib().bn_relu_pool_fwd_eval_f32(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                    running_mean.data_ptr(), running_var.data_ptr(), b, h, c, eps,
+                                    _stream())
+    return y
+
+
+def bn_relu_pool_bwd_f32(x, dy, gamma, beta, save_mean, save_rstd):
+    """Backward of bn_relu_pool_fwd_train_f32: x the conv output, dy the pooled gradient; returns
+    (dx at full resolution, dgamma, dbeta)."""
+    _req(x, F32, "x", 4)
+    _req(dy, F32, "dy", 4)
+    b, h, w, c = x.shape
+    if tuple(dy.shape) != (b, h // 2, w // 2, c) or h != w or h % 2:
+        raise ValueError("bn_relu_pool_bwd_f32: shape mismatch")
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=F32, device=x.device)
+    dbeta = torch.empty(c, dtype=F32, device=x.device)
+    lib().bn_relu_pool_bwd_f32(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(),
+                               beta.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
+                               dgamma.data_ptr(), dbeta.data_ptr(), _reduce_ws(x.device).data_ptr(),
+                               b, h, c, _stream())
+    return dx, dgamma, dbeta
+
+
 def column_sum_f32(x):
     _req(x, F32, "x")
     c = x.shape[-1]

@@ -114,6 +114,7 @@ def test_fp32_engine_layer_by_layer(batch_norm, batch):
     # ------------------------------------------------------------------ forward
     inp = x.double()
     layer_in = []
+    rebuilt, sure_windows = {}, {}
     for L, (cin, cout, hw, pool, pre_off, out_off, pool_off, gout_off) in enumerate(table):
         layer_in.append(inp)
         w = convs[L].weight.detach().double()
@@ -129,6 +130,19 @@ def test_fp32_engine_layer_by_layer(batch_norm, batch):
             expect(f"bn{L} rstd", nb.workspace[so + cout:so + 2 * cout], (var + 1e-5).rsqrt(), 1e-5)
             z = F.batch_norm(pre, None, None, bns[L].weight.detach().double(),
                              bns[L].bias.detach().double(), True, 0.1, 1e-5)
+            if pool:
+                # BatchNorm + ReLU + pool run fused: the full-resolution activation is never
+                # stored.  It is rebuilt here; windows whose winner (or whose sign) another
+                # arithmetic could decide differently are left out of the backward comparison.
+                out = z.relu()
+                rebuilt[L] = z
+                win = z.view(B, cout, hw // 2, 2, hw // 2, 2).permute(0, 1, 2, 4, 3, 5)
+                top = win.reshape(B, cout, hw // 2, hw // 2, 4).topk(2, dim=-1).values
+                ok = (top[..., 0].abs() > 1e-4) & ((top[..., 0] - top[..., 1] > 1e-4) | (top[..., 0] < 0))
+                sure_windows[L] = ok.repeat_interleave(2, 2).repeat_interleave(2, 3)
+                expect(f"bn{L} + pool fwd", act(pool_off, hw // 2, cout), F.max_pool2d(out, 2))
+                inp = act(pool_off, hw // 2, cout)
+                continue
             sure = z.abs() > 1e-5
             expect(f"bn{L} fwd", out * sure, z.relu() * sure)
         else:
@@ -152,13 +166,19 @@ def test_fp32_engine_layer_by_layer(batch_norm, batch):
     arriving = (dl @ ref.fc1.weight.detach().double()).view(B, -1, 1, 1)
     for L in range(len(table) - 1, -1, -1):
         cin, cout, hw, pool, pre_off, out_off, pool_off, gout_off = table[L]
-        out = act(out_off, hw, cout)
-        g = arriving
-        if pool:
-            o = out.clone().requires_grad_(True)
-            F.max_pool2d(o, 2).backward(g)
-            g = o.grad
-        g = g * (out > 0)                       # the ReLU decisions the engine's forward took
+        if L in rebuilt:
+            # the gradient goes to each window's winner where the engine's pooled output says
+            # the window was alive
+            _, idx = F.max_pool2d(rebuilt[L], 2, return_indices=True)
+            g = F.max_unpool2d(arriving * (act(pool_off, hw // 2, cout) > 0), idx, 2)
+        else:
+            out = act(out_off, hw, cout)
+            g = arriving
+            if pool:
+                o = out.clone().requires_grad_(True)
+                F.max_pool2d(o, 2).backward(g)
+                g = o.grad
+            g = g * (out > 0)                   # the ReLU decisions the engine's forward took
         if batch_norm:
             pre = act(pre_off, hw, cout)
             so = saves[L]
@@ -175,7 +195,10 @@ def test_fp32_engine_layer_by_layer(batch_norm, batch):
         else:
             expect(f"conv{L} db", grads[conv_names[L] + ".bias"], g.sum((0, 2, 3)))
         gout = act(gout_off, hw, cout)
-        expect(f"layer{L} dL/d(conv out)", gout, g)
+        if L in sure_windows:
+            expect(f"layer{L} dL/d(conv out)", gout * sure_windows[L], g * sure_windows[L])
+        else:
+            expect(f"layer{L} dL/d(conv out)", gout, g)
         # from here on the engine's own gradient tensor: each kernel is checked in isolation
         dw = torch.nn.grad.conv2d_weight(layer_in[L], (cout, cin, 3, 3), gout, padding=1)
         expect(f"conv{L} dW", grads[conv_names[L] + ".weight"], dw)

@@ -151,6 +151,55 @@ def test_bn_relu_f32(rows, c):
     check("bn eval", ye, (g64 * (x64 - rm.double()) * (rv.double() + 1e-5).rsqrt() + b64).relu())
 
 
+@pytest.mark.parametrize("batch,hw,c", [(2, 32, 64), (256, 32, 64), (256, 16, 128), (64, 8, 256),
+                                        (256, 4, 512), (256, 2, 512), (3, 2, 512)])
+def test_bn_relu_pool_f32(batch, hw, c):
+    """BatchNorm + ReLU + 2x2 max-pool fused, fp32: against the float64 composition of the three
+    ops.  Backward is compared on the windows whose winner and sign are beyond doubt (two window
+    positions within 1e-4 of each other, or a maximum within 1e-4 of zero, may be decided either
+    way by another arithmetic)."""
+    n = native()
+    x = rand(batch, hw, hw, c, seed=19) * 2 + 0.5
+    gamma = rand(c, seed=20) * 0.2 + 1
+    beta = rand(c, scale=0.3, seed=21)
+    rm = torch.zeros(c, device=DEV)
+    rv = torch.ones(c, device=DEV)
+    y, mean, rstd = n.bn_relu_pool_fwd_train_f32(x, gamma, beta, rm, rv)
+    rows = batch * hw * hw
+    x64 = x.double()
+    m64, v64 = x64.mean((0, 1, 2)), x64.var((0, 1, 2), unbiased=False)
+    r64 = (v64 + 1e-5).rsqrt()
+    xh = (x64 - m64) * r64
+    z = gamma.double() * xh + beta.double()
+    zr = z.permute(0, 3, 1, 2)
+    check("bn+pool fwd", nchw(y), F.max_pool2d(zr.relu(), 2))
+    check("bn+pool save_mean", mean, m64, tol=1e-5)
+    check("bn+pool save_rstd", rstd, r64, tol=1e-5)
+    check("bn+pool running_mean", rm, 0.1 * m64)
+    check("bn+pool running_var", rv, 0.9 + 0.1 * x64.var((0, 1, 2), unbiased=True))
+    ye = n.bn_relu_pool_fwd_eval_f32(x, gamma, beta, rm, rv)
+    ze = gamma.double() * (x64 - rm.double()) * (rv.double() + 1e-5).rsqrt() + beta.double()
+    check("bn+pool eval", nchw(ye), F.max_pool2d(ze.permute(0, 3, 1, 2).relu(), 2))
+
+    dy = rand(batch, hw // 2, hw // 2, c, seed=22)
+    dx, dgamma, dbeta = n.bn_relu_pool_bwd_f32(x, dy.clone(), gamma, beta, mean, rstd)
+    # dL/dz: the pooled gradient at each window's winner, where the kernel's own output says the
+    # window was alive (a sum over millions of windows would otherwise hinge on a maximum within
+    # fp32 rounding of zero)
+    _, idx = F.max_pool2d(zr, 2, return_indices=True)
+    g = F.max_unpool2d(nchw(dy) * (nchw(y) > 0), idx, 2).permute(0, 2, 3, 1)
+    db_ref, dg_ref = g.sum((0, 1, 2)), (g * xh).sum((0, 1, 2))
+    win = z.view(batch, hw // 2, 2, hw // 2, 2, c).permute(0, 1, 3, 5, 2, 4)
+    top = win.reshape(batch, hw // 2, hw // 2, c, 4).topk(2, dim=-1).values
+    ok = (top[..., 0].abs() > 1e-4) & ((top[..., 0] - top[..., 1] > 1e-4) | (top[..., 0] < 0))
+    assert float(ok.double().mean()) > 0.99
+    ok = ok.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    check("bn+pool dbeta", dbeta, db_ref, tol=2e-4)
+    check("bn+pool dgamma", dgamma, dg_ref, tol=2e-4)
+    want = gamma.double() * r64 * (g - db_ref / rows - xh * dg_ref / rows)
+    check("bn+pool dx", dx * ok, want * ok, tol=2e-4)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_bn_statistics_survive_a_large_mean(dtype):
     """A channel whose mean is 100x its standard deviation: E[x^2] - E[x]^2 in fp32 would lose
