@@ -112,6 +112,7 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
                      int num_classes)
     : max_batch_(max_batch), num_classes_(num_classes), bn_(batch_norm) {
     if (max_batch <= 0) throw std::invalid_argument("VggEngine: batch must be positive");
+    if (const char* e = getenv("DML_BN_EPI_SUMS")) plain_epi_sums_ = atoi(e) != 0;      // tuning
     const ParamLayout lay = plan_parameters(widths, batch_norm, num_classes);
     for (const ParamLayout::Conv& l : lay.convs) {
         Conv c;
@@ -564,7 +565,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
         else if (bn_)
             bn_relu_bwd(arena_ + c.pre_off, transit, g, params_ + c.gamma_off, params_ + c.beta_off,
                         ws_ + c.save_off, ws_ + c.save_off + c.cout, grads_ + c.gamma_off,
-                        grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream, pending);
+                        grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream, pending, bn_sums);
         if (g_on_the_fly && !bn_) {
             conv1_wgrad_relu_pool(x, arena_ + c.out_off, transit, grads_ + c.w_off,
                                   grads_ + c.b_off, batch, slab, stream);
@@ -610,8 +611,11 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             const bool defer_sum = bn_ && !bn_bwd_single_launch(
                 batch * c.hw * c.hw, c.cin);
             BnPoolReduce red;
-            const bool want_sums = bn_ && prev.pool_after;
+            // (without a pool behind the previous layer the same epilogue leaves the sums of the
+            // plain BatchNorm backward reduction; DML_BN_EPI_SUMS=0 keeps that in its own pass)
+            const bool want_sums = bn_ && (prev.pool_after || plain_epi_sums_);
             if (want_sums) {
+                red.pooled = prev.pool_after;
                 red.pre = arena_ + prev.pre_off;
                 red.gamma = params_ + prev.gamma_off; red.beta = params_ + prev.beta_off;
                 red.mean = ws_ + prev.save_off; red.rstd = ws_ + prev.save_off + prev.cout;

@@ -180,6 +180,7 @@ class VggEngine {
     size_t shadow_off_ = 0, w1_off_ = 0, gin_off_ = 0;
     size_t logits_off_ = 0, dlogits_off_ = 0, loss_off_ = 0, stats_off_ = 0, slab_off_ = 0,
            cstats_off_ = 0, fc_ws_off_ = 0;
+    bool plain_epi_sums_ = true;   // BatchNorm backward sums of un-pooled layers from the dgrad epilogue
     SlabSumJobs wgrad_sums_;      // partial-result reductions not yet launched
     size_t slab_elems_ = 0;
     std::vector<SlotInfo> slots_, bn_slots_;

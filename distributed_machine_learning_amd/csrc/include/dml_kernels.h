@@ -58,10 +58,13 @@ struct SplitSlabs {
 // partial row per pixel tile in `partials` ([tile][2][N] floats) - the reduction pass of
 // bn_relu_pool_bwd, which would re-read this gradient and the conv output, is then not needed.
 // Applied only by plans that keep a pixel tile in one block (reported through *bn_done).
+// With `pooled == false` the layer has no pool: `pre` has the shape of this convolution's output
+// and every element is its own "winner" (the sums of bn_relu_bwd's reduction pass).
 struct BnPoolReduce {
-    const bf16_raw* pre = nullptr;      // the pooled layer's conv output [batch][2hw][2hw][N]
+    const bf16_raw* pre = nullptr;      // the layer's conv output [batch][2hw][2hw][N] ([hw][hw] unpooled)
     const float *gamma = nullptr, *beta = nullptr, *mean = nullptr, *rstd = nullptr;
     float* partials = nullptr;
+    bool pooled = true;
 };
 
 // Implicit GEMM  y[m][n] = sum_{tap,c} x[m (+) tap][c] * w[n][tap][c],  m = (b,h,w) NHWC.
@@ -205,7 +208,9 @@ size_t bn_workspace_elems();
 void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
                  const float* beta, const float* save_mean, const float* save_rstd,
                  float* dgamma, float* dbeta, float* stats_ws, int rows, int c,
-                 hipStream_t stream, SplitSlabs dy_slabs = {});
+                 hipStream_t stream, SplitSlabs dy_slabs = {}, BnPartials sums = {});
+// (`sums`: the dbeta / dgamma partial rows were already produced by the convolution that wrote
+// dy, see BnPoolReduce - the reduction pass is skipped)
 
 // True when bn_relu_bwd / bn_relu_pool_bwd handle a gradient of `dy_rows` rows x c channels in a
 // single launch (small layers) - provided dy is a stored tensor, not unsummed split slabs.

@@ -369,8 +369,22 @@ bool bn_bwd_fold_apply_plain(const T* x, const T* dy, T* dx, const float* gamma,
 void bn_relu_bwd(const bf16_raw* x, bf16_raw* dy, bf16_raw* dx, const float* gamma,
                  const float* beta, const float* save_mean, const float* save_rstd,
                  float* dgamma, float* dbeta, float* ws, int rows, int c, hipStream_t stream,
-                 SplitSlabs sl) {
+                 SplitSlabs sl, BnPartials sums) {
     check(rows, c, "bn_relu_bwd");
+    if (sums.data) {            // the producer of dy already left the sums, one partial row per tile
+        if (sl.splits > 0 || sums.rows <= 0)
+            throw std::invalid_argument("bn_relu_bwd: inconsistent partial sums");
+        if (bn_bwd_fold_apply_plain<uint16_t>(x, dy, dx, gamma, beta, save_mean, save_rstd, sums.data,
+                                              sums.rows, dgamma, dbeta, rows, c, stream))
+            return;
+        hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(fold_blocks(c)), dim3(256), 0, stream,
+                           (const float*)sums.data, dgamma, dbeta, sums.rows, c);
+        const size_t total8 = (size_t)rows * (c / 8);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<uint16_t>, dim3(apply_blocks(total8)), dim3(256), 0,
+                           stream, x, (const uint16_t*)dy, dx, gamma, beta, save_mean, save_rstd,
+                           (const float*)dgamma, (const float*)dbeta, rows, c, total8);
+        return;
+    }
     if (bn_relu_bwd_small(x, dy, dx, gamma, beta, save_mean, save_rstd, dgamma, dbeta, rows, c,
                           stream, sl))
         return;

@@ -66,6 +66,7 @@ struct IgemmArgs {
     // layer's conv output and constants; the partial rows go to `stats`
     const uint16_t* bn_pre;
     const float *bn_gamma, *bn_beta, *bn_mean, *bn_rstd;
+    int bn_pooled;        // 0: the layer has no pool, bn_pre has this output's shape
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -211,6 +212,76 @@ __device__ __forceinline__ void bn_pool_bwd_tile_sums(const f32x4 (&acc)[TN][TM]
                 s2[i][c] += gi * __builtin_fmaf(xw, rs[i][c], -mrs[i][c]);
             }
         }
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s1[i][c] = row16_sum(s1[i][c]);
+            s2[i][c] = row16_sum(s2[i][c]);
+        }
+}
+
+// The same sums for a layer WITHOUT a pool behind its ReLU: the tile holds the gradient of the
+// layer's activation itself, element (m, col) pairs with conv output element (m, col); the mask is
+// forward's ReLU decision re-derived with forward's scale / shift (as in bn_bwd_reduce_kernel).
+// The conv output values of the tile are requested a few K steps before the loop ends
+// (bn_plain_bwd_prefetch), so their round trip is over when the accumulators are.
+template <int TN, int TM>
+__device__ __forceinline__ void bn_plain_bwd_prefetch(const IgemmArgs& p, int m_first, int nl,
+                                                      uint32_t (&xv)[TM][2 * TN]) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m_first + j * 16;
+        const bool in = m < p.M;
+        const uint16_t* px = p.bn_pre + ((size_t)(in ? m : 0) * p.N + nl);
+        if constexpr (TN % 2 == 0) {
+#pragma unroll
+            for (int h = 0; h < TN / 2; ++h) {
+                const uint4 t = *(const uint4*)(px + 8 * h);
+                xv[j][4 * h] = t.x; xv[j][4 * h + 1] = t.y;
+                xv[j][4 * h + 2] = t.z; xv[j][4 * h + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const uint2 t = *(const uint2*)(px + 4 * i);
+                xv[j][2 * i] = t.x; xv[j][2 * i + 1] = t.y;
+            }
+        }
+    }
+}
+
+template <int TN, int TM>
+__device__ __forceinline__ void bn_plain_bwd_tile_sums(const f32x4 (&acc)[TN][TM], const IgemmArgs& p,
+                                                       const uint32_t (&xv)[TM][2 * TN], int m_first,
+                                                       int nl, float (&s1)[TN][4], float (&s2)[TN][4]) {
+    float ysc[TN][4], ysh[TN][4], rs[TN][4], mrs[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = nl + 4 * i + c;
+            rs[i][c] = p.bn_rstd[col];
+            mrs[i][c] = p.bn_mean[col] * rs[i][c];
+            ysc[i][c] = p.bn_gamma[col] * rs[i][c];
+            ysh[i][c] = p.bn_beta[col] - p.bn_mean[col] * ysc[i][c];
+            s1[i][c] = s2[i][c] = 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        if (m_first + j * 16 >= p.M) continue;      // (the row loaded in its place adds nothing)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t word = xv[j][2 * i + (c >> 1)];
+                const float v = bf16_bits_to_float((uint16_t)((c & 1) ? (word >> 16) : (word & 0xffff)));
+                const float d = bf16_bits_to_float(float_to_bf16_bits(acc[i][j][c]));
+                const float gi = (__builtin_fmaf(v, ysc[i][c], ysh[i][c]) > 0.f) ? d : 0.f;
+                s1[i][c] += gi;
+                s2[i][c] += gi * (v * rs[i][c] - mrs[i][c]);
+            }
     }
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -402,6 +473,17 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
 #pragma unroll
     for (int s = 0; s < D; ++s)
         if (s < steps) issue(s);
+    // (the un-pooled BatchNorm backward sums of the epilogue want the layer's conv output values
+    // of this tile: requested four K steps before the end, see bn_plain_bwd_prefetch)
+    constexpr bool kBnBwd = EPI == EPI_NONE && !SPLIT && !PM;
+    uint32_t bn_xv[kBnBwd ? TM : 1][2 * TN];
+    const bool bn_plain = kBnBwd && p.bn_pre != nullptr && !p.bn_pooled;
+    auto bn_prefetch = [&]() {
+        if constexpr (kBnBwd)
+            bn_plain_bwd_prefetch<TN, TM>(p, m0 + wm * WTM + (lane & 15),
+                                          n0 + wn * WTN + (lane >> 4) * 4 * TN, bn_xv);
+    };
+    const int bn_fetch_step = steps > 5 ? steps - 5 : 0;
     if (steps > 0) {
         bf16x8 wfa[TN], xfa[TM], wfb[TN], xfb[TM];
         wait_step(0);
@@ -421,9 +503,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (s + 1 + D < steps) issue(s + 1 + D);
+            if (bn_plain && s == bn_fetch_step) bn_prefetch();
             load_frags((s + 1) % NS, 0, wfa, xfa);
             mma(wfb, xfb);
         }
+        if (bn_plain && steps < 2) bn_prefetch();      // (the loop above did not run)
         load_frags((steps - 1) % NS, 1, wfb, xfb);
         mma(wfa, xfa);
         mma(wfb, xfb);
@@ -441,9 +525,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
     if (!SPLIT && p.stats && (EPI == EPI_BIAS || bn_bwd)) {
         float s1[TN][4], s2[TN][4];
         if (bn_bwd) {
-            if constexpr (EPI == EPI_NONE && !SPLIT && !PM)
-                bn_pool_bwd_tile_sums<TN, TM>(acc, p, m0 + wm * WTM + l15,
-                                              n0 + wn * WTN + lq * 4 * TN, s1, s2);
+            if constexpr (EPI == EPI_NONE && !SPLIT && !PM) {
+                if (p.bn_pooled)
+                    bn_pool_bwd_tile_sums<TN, TM>(acc, p, m0 + wm * WTM + l15,
+                                                  n0 + wn * WTN + lq * 4 * TN, s1, s2);
+                else
+                    bn_plain_bwd_tile_sums<TN, TM>(acc, p, bn_xv, m0 + wm * WTM + l15,
+                                                   n0 + wn * WTN + lq * 4 * TN, s1, s2);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < TN; ++i)
@@ -837,6 +926,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(IgemmArgs p) {
         }
     };
 
+    // (un-pooled BatchNorm backward sums in the epilogue: the layer's conv output values of this
+    // tile are requested at the start of the last chunk, see bn_plain_bwd_prefetch)
+    constexpr bool kBnBwd = EPI == EPI_NONE;
+    uint32_t bn_xv[kBnBwd ? TM : 1][2 * TN];
+    const bool bn_plain = kBnBwd && p.bn_pre != nullptr && !p.bn_pooled;
     issue_patch(0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
@@ -861,6 +955,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(IgemmArgs p) {
                 if (c2 < chunks) issue_w(c2, t2, (t + 2) % 3);
             }
             if (t == 0 && !last) issue_patch(cc + 1);
+            if constexpr (kBnBwd)
+                if (bn_plain && t == 0 && last)
+                    bn_plain_bwd_prefetch<TN, TM>(p, m0 + wm * WTM + l15,
+                                                  n0 + wn * WTN + lq * 4 * TN, bn_xv);
             compute(t % 3, cc, t);
         }
     }
@@ -869,9 +967,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(IgemmArgs p) {
     if (p.stats && (EPI == EPI_BIAS || bn_bwd)) {
         float s1[TN][4], s2[TN][4];
         if (bn_bwd) {
-            if constexpr (EPI == EPI_NONE)
-                bn_pool_bwd_tile_sums<TN, TM>(acc, p, m0 + wm * WTM + l15,
-                                              n0 + wn * WTN + lq * 4 * TN, s1, s2);
+            if constexpr (EPI == EPI_NONE) {
+                if (p.bn_pooled)
+                    bn_pool_bwd_tile_sums<TN, TM>(acc, p, m0 + wm * WTM + l15,
+                                                  n0 + wn * WTN + lq * 4 * TN, s1, s2);
+                else
+                    bn_plain_bwd_tile_sums<TN, TM>(acc, p, bn_xv, m0 + wm * WTM + l15,
+                                                   n0 + wn * WTN + lq * 4 * TN, s1, s2);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < TN; ++i)
@@ -1007,6 +1110,7 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.mask = mask; a.slab = workspace;
     a.stats = stats;
     a.bn_pre = nullptr; a.bn_gamma = a.bn_beta = a.bn_mean = a.bn_rstd = nullptr;
+    a.bn_pooled = 1;
     if (stats && (epi != EPI_BIAS || force_plan))
         throw std::invalid_argument("conv3x3_igemm: statistics come with the default plan and "
                                     "the bias-only epilogue");
@@ -1031,6 +1135,7 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
         a.bn_pre = bn_pool->pre;
         a.bn_gamma = bn_pool->gamma; a.bn_beta = bn_pool->beta;
         a.bn_mean = bn_pool->mean; a.bn_rstd = bn_pool->rstd;
+        a.bn_pooled = bn_pool->pooled ? 1 : 0;
         a.stats = bn_pool->partials;
         *bn_done = BnPartials{bn_pool->partials, (a.M + pl.bm - 1) / pl.bm, nullptr};
     }
