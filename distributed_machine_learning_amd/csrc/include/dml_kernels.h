@@ -130,6 +130,7 @@ void set_wgrad_variant(int variant);
 // Tuning: blocks every conv3x3_wgrad launch aims for, overriding the caller's split_target
 // (0 = no override).  Like the variant, set it before engines are built (slab sizing).
 void set_wgrad_block_target(int blocks);
+void set_wgrad_kstep(int pixels);      // per-tap kernel: pixels per K step, 64 (default) or 32
 // Tuning: co tile (0 = 128 where it divides cout) and LDS ring depth of the tap-resident kernel
 // when conv3x3_wgrad dispatches to it.
 void set_wgrad9_config(int bco, int stages);

@@ -65,16 +65,19 @@ struct WgradArgs {
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4w;
 constexpr int kOutOfRangeW = (int)0x80000000;
 
-template <int BCO, int BCI>
+// KS = pixels per K step: 64, or 32 - half the LDS (40 KB for a 128 x 128 tile), so that more
+// blocks, or a block of another kernel, fit next to one on a CU.
+template <int BCO, int BCI, int KS>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
     constexpr int SA = BCO * 2 + 64;          // dy tile row stride (bytes)
     constexpr int SB = BCI * 2 + 64;          // x  tile row stride
-    constexpr int STAGE = 64 * (SA + SB);
+    constexpr int STAGE = KS * (SA + SB);
     constexpr int WCO = BCO / 2, WCI = BCI / 2;      // wave tile
     constexpr int TCO = WCO / 32, TCI = WCI / 32;
     constexpr int A_CH = BCO / 8, B_CH = BCI / 8;    // 16-byte chunks per row
-    constexpr int A_IT = 64 * A_CH / 256, B_IT = 64 * B_CH / 256;
+    constexpr int A_IT = KS * A_CH / 256, B_IT = KS * B_CH / 256;
     static_assert(TCO >= 1 && TCI >= 1, "wave tile too small");
+    static_assert(A_IT >= 1 && B_IT >= 1 && (KS == 32 || KS == 64), "K step too short for this tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
     const int dh = tap / 3 - 1, dw_ = tap % 3 - 1;
     const int hw = p.hw;
 
-    const int total_steps = (p.M + 63) / 64;
+    const int total_steps = (p.M + KS - 1) / KS;
     const int s_begin = split * p.steps_per_split;
     const int s_end = min(total_steps, s_begin + p.steps_per_split);
 
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
         __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
     u32x4w ra[A_IT], rb[B_IT];
     auto load_step = [&](int s) {
-        const int pbase = s * 64;
+        const int pbase = s * KS;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int pix = pbase + a_r + i * A_RSTEP;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
     };
     auto store_step = [&](int stage) {
         char* sA = smem + stage * STAGE;
-        char* sB = sA + 64 * SA;
+        char* sB = sA + KS * SA;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
             *(u32x4w*)(sA + (a_r + i * A_RSTEP) * SA + a_c * 16) = ra[i];
@@ -156,12 +159,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
     const int frag_row = 8 * (g >> 1) + q;
     const int frag_col = 16 * (g & 1) + 4 * pp;
     const int a_off = frag_row * SA + (wco * WCO + frag_col) * 2;
-    const int b_off = 64 * SA + frag_row * SB + (wci * WCI + frag_col) * 2;
+    const int b_off = KS * SA + frag_row * SB + (wci * WCI + frag_col) * 2;
 
     auto compute = [&](int stage) {
         const char* base = smem + stage * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS / 16; ++ks) {
             bf16x8 af[TCO], bfr[TCI];
 #pragma unroll
             for (int i = 0; i < TCO; ++i)
@@ -253,14 +256,14 @@ int wgrad_tiles(const ConvShape& s) {
     return (s.cout / bco) * (s.cin / bci) * 9;
 }
 
-template <int BCO, int BCI>
-void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab,
-                  int split_target) {
+template <int BCO, int BCI, int KS>
+void launch_wgrad_ks(WgradArgs a, hipStream_t stream, int force_splits, float* slab,
+                     int split_target) {
     a.tiles_co = a.Cout / BCO;
     a.tiles_ci = a.Cin / BCI;
     const int tiles = a.tiles_co * a.tiles_ci * 9;
     const SplitPlan sp = plan_splits(a.M, tiles, force_splits, slab != nullptr, split_target);
-    a.steps_per_split = sp.steps_per_split;
+    a.steps_per_split = sp.steps_per_split * (64 / KS);     // (the plan counts 64-pixel steps)
     a.split_stride = 0;
     a.atomic = sp.splits > 1 ? 1 : 0;
     if (slab && sp.splits > 1) {        // deterministic: one partial result per split, no atomics
@@ -268,15 +271,24 @@ void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab
         a.split_stride = (size_t)a.Cout * 9 * a.Cin;
         a.atomic = 0;
     }
-    constexpr int lds = 2 * 64 * ((BCO * 2 + 64) + (BCI * 2 + 64));
+    constexpr int lds = 2 * KS * ((BCO * 2 + 64) + (BCI * 2 + 64));
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<BCO, BCI>,
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<BCO, BCI, KS>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<BCO, BCI>), dim3(tiles, sp.splits), dim3(256), lds,
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<BCO, BCI, KS>), dim3(tiles, sp.splits), dim3(256), lds,
                        stream, a);
+}
+
+int g_kstep = 64;       // pixels per K step of the per-tap kernel (tuning: 32)
+
+template <int BCO, int BCI>
+void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab,
+                  int split_target) {
+    if (g_kstep == 32) launch_wgrad_ks<BCO, BCI, 32>(a, stream, force_splits, slab, split_target);
+    else launch_wgrad_ks<BCO, BCI, 64>(a, stream, force_splits, slab, split_target);
 }
 
 }  // namespace
@@ -309,6 +321,10 @@ void set_wgrad9_config(int bco, int stages) {
         throw std::invalid_argument("set_wgrad9_config: bco in {0, 64, 128}, stages in {2, 3}");
     g_bco = bco;
     g_stages = stages;
+}
+void set_wgrad_kstep(int pixels) {
+    if (pixels != 32 && pixels != 64) throw std::invalid_argument("set_wgrad_kstep: 32 or 64");
+    g_kstep = pixels;
 }
 void set_wgrad_block_target(int blocks) {
     if (blocks < 0) throw std::invalid_argument("set_wgrad_block_target: negative");

@@ -56,6 +56,8 @@ class NativeBackend:
             C.set_wgrad9_config(int(bco), int(stages))
         if os.environ.get("DML_WGRAD_TARGET"):
             C.set_wgrad_block_target(int(os.environ["DML_WGRAD_TARGET"]))
+        if os.environ.get("DML_WGRAD_KSTEP"):
+            C.set_wgrad_kstep(int(os.environ["DML_WGRAD_KSTEP"]))
         self.engine = engine_cls(widths, cfg.batch_size, cfg.batch_norm, cfg.num_classes)
         e = self.engine
         f32 = dict(dtype=torch.float32, device=device)
