@@ -113,6 +113,7 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
     : max_batch_(max_batch), num_classes_(num_classes), bn_(batch_norm) {
     if (max_batch <= 0) throw std::invalid_argument("VggEngine: batch must be positive");
     if (const char* e = getenv("DML_BN_EPI_SUMS")) plain_epi_sums_ = atoi(e) != 0;      // tuning
+    if (const char* e = getenv("DML_WGRAD_TUNED")) tuned_wgrad_splits_ = atoi(e) != 0;  // tuning
     const ParamLayout lay = plan_parameters(widths, batch_norm, num_classes);
     for (const ParamLayout::Conv& l : lay.convs) {
         Conv c;
@@ -203,13 +204,25 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
     }
     // wgrad partial results, one slab per split (summed by a batched kernel: deterministic,
     // and plain stores run ~4x faster than float atomics)
+    wgrad_force_splits_.assign(convs_.size(), 0);
+    if (const char* e = getenv("DML_WGRAD_SPLITS")) {      // tuning: "s1,s2,..." for conv layers 1..
+        size_t i = 1;
+        for (const char* q = e; *q && i < convs_.size(); ++i) {
+            wgrad_force_splits_[i] = atoi(q);
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
     for (size_t i = 0; i < convs_.size(); ++i) {
         Conv& c = convs_[i];
         c.wslab_off = w;
         if (i == 0) continue;
         // (room for either block target, see wgrad_split_target())
         const ConvShape ws_shape = {max_batch_, c.hw, c.cin, c.cout};
-        const int splits = conv3x3_wgrad_max_splits(ws_shape);
+        int splits = conv3x3_wgrad_max_splits(ws_shape);
+        if (wgrad_force_splits_[i] > splits) splits = wgrad_force_splits_[i];
+        const int tuned = conv3x3_wgrad_tuned_splits({256, c.hw, c.cin, c.cout}, bn_);
+        if (max_batch_ >= 256 && tuned > splits) splits = tuned;
         if (splits > 1) w = align_up(w + (size_t)splits * c.cout * 9 * c.cin);
     }
     ws_elems_ = w;
@@ -309,8 +322,13 @@ void VggEngine::launch_wgrad(int i, int batch, hipStream_t stream) {
     // nothing else in a backward pass touches the reduction scratch.
     if (!bn_) column_sum(g, grads_ + c.b_off, batch * c.hw * c.hw, c.cout, ws_ + stats_off_, stream);
     const int target = wgrad_split_target();
-    conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream, 0, ws_ + c.wslab_off, target);
-    const int splits = conv3x3_wgrad_splits(s, target);
+    // pixel splits: the tuning override, else the list tuned inside the step for this shape, else
+    // the kernel's plan for the block target
+    int forced = wgrad_force_splits_[i];
+    if (forced == 0 && tuned_wgrad_splits_) forced = conv3x3_wgrad_tuned_splits(s, bn_);
+    conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream, forced, ws_ + c.wslab_off, target);
+    const int splits = forced > 0 ? conv3x3_wgrad_forced_splits(s, forced)
+                                  : conv3x3_wgrad_splits(s, target);
     if (splits > 1) {       // partial results per split, summed by flush_wgrad_sums
         if (wgrad_sums_.n == SlabSumJobs::kMax) flush_wgrad_sums(stream);
         const int j = wgrad_sums_.n++;

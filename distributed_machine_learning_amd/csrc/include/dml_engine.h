@@ -200,6 +200,8 @@ class VggEngine {
     std::vector<hipEvent_t> hand_off_;      // per layer: main-stream position the side stream waits for
     hipEvent_t side_done_ = nullptr;
     std::vector<int> wgrad_queue_;          // layers whose gradient is ready, wgrad not yet launched
+    bool tuned_wgrad_splits_ = true;        // use conv3x3_wgrad_tuned_splits where it has an entry
+    std::vector<int> wgrad_force_splits_;   // tuning (DML_WGRAD_SPLITS): pixel splits per conv layer, 0 = planned
     bool side_done_recorded_ = false;
     bool side_busy_ = false;                // side-stream work the main stream has not waited for
     hipGraph_t graph_ = nullptr;

@@ -120,6 +120,9 @@ void conv3x3_wgrad(const bf16_raw* x, const bf16_raw* dy, float* dw, ConvShape s
                    hipStream_t stream, int force_splits = 0 /* tuning */, float* slab = nullptr,
                    int split_target = 0 /* blocks to aim for, 0: the kernel's own optimum */);
 int conv3x3_wgrad_splits(ConvShape s, int split_target = 0);
+int conv3x3_wgrad_forced_splits(ConvShape s, int force_splits);
+// pixel splits tuned inside the training step for the shapes of the flagship run (0: none)
+int conv3x3_wgrad_tuned_splits(ConvShape s, bool batch_norm);
 // the largest split count any kernel choice / block target can ask for at any batch size up to
 // s.batch (slab sizing)
 int conv3x3_wgrad_max_splits(ConvShape s);
@@ -130,6 +133,7 @@ void set_wgrad_variant(int variant);
 // Tuning: blocks every conv3x3_wgrad launch aims for, overriding the caller's split_target
 // (0 = no override).  Like the variant, set it before engines are built (slab sizing).
 void set_wgrad_block_target(int blocks);
+void set_wgrad_waves(int waves);       // per-tap kernel: waves per block, 4 (default) or 8
 void set_wgrad_kstep(int pixels);      // per-tap kernel: pixels per K step, 64 (default) or 32
 // Tuning: co tile (0 = 128 where it divides cout) and LDS ring depth of the tap-resident kernel
 // when conv3x3_wgrad dispatches to it.

@@ -67,22 +67,28 @@ constexpr int kOutOfRangeW = (int)0x80000000;
 
 // KS = pixels per K step: 64, or 32 - half the LDS (40 KB for a 128 x 128 tile), so that more
 // blocks, or a block of another kernel, fit next to one on a CU.
-template <int BCO, int BCI, int KS>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
+// NW = waves per block: 4 (2 x 2 wave tiles), or 8 - two waves per SIMD of the CU a block mostly
+// has to itself, so one wave's LDS and barrier waits hide behind the other's MFMAs (the wave tile
+// shrinks to a quarter of the longer tile side: 50 % more LDS fragment reads per step).
+template <int BCO, int BCI, int KS, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_kernel(WgradArgs p) {
     constexpr int SA = BCO * 2 + 64;          // dy tile row stride (bytes)
     constexpr int SB = BCI * 2 + 64;          // x  tile row stride
     constexpr int STAGE = KS * (SA + SB);
-    constexpr int WCO = BCO / 2, WCI = BCI / 2;      // wave tile
+    constexpr int NT = NW * 64;
+    // wave grid: 2 x 2, or with eight waves 2 x 4 (4 x 2 when the ci tile is the narrow one)
+    constexpr int WAVES_CO = NW == 4 ? 2 : (BCI >= BCO ? 2 : 4), WAVES_CI = NW / WAVES_CO;
+    constexpr int WCO = BCO / WAVES_CO, WCI = BCI / WAVES_CI;      // wave tile
     constexpr int TCO = WCO / 32, TCI = WCI / 32;
     constexpr int A_CH = BCO / 8, B_CH = BCI / 8;    // 16-byte chunks per row
-    constexpr int A_IT = KS * A_CH / 256, B_IT = KS * B_CH / 256;
+    constexpr int A_IT = KS * A_CH / NT, B_IT = KS * B_CH / NT;
     static_assert(TCO >= 1 && TCI >= 1, "wave tile too small");
     static_assert(A_IT >= 1 && B_IT >= 1 && (KS == 32 || KS == 64), "K step too short for this tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wco = wave & 1, wci = wave >> 1;
+    const int wco = wave % WAVES_CO, wci = wave / WAVES_CO;
 
     // Workgroups go round-robin to the 8 XCDs (own L2 each) in launch order.  Renumber so
     // that an XCD owns a contiguous range of pixel splits for ALL tiles: the dy / x pixels of a
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
 
     const int a_c = tid % A_CH, a_r = tid / A_CH;       // dy staging ownership
     const int b_c = tid % B_CH, b_r = tid / B_CH;       // x staging ownership
-    constexpr int A_RSTEP = 256 / A_CH, B_RSTEP = 256 / B_CH;
+    constexpr int A_RSTEP = NT / A_CH, B_RSTEP = NT / B_CH;
 
     // Both operands are fetched through raw buffer descriptors; rows past the end and taps
     // that fall into the padding get an out-of-range offset, for which the hardware returns
@@ -256,7 +262,7 @@ int wgrad_tiles(const ConvShape& s) {
     return (s.cout / bco) * (s.cin / bci) * 9;
 }
 
-template <int BCO, int BCI, int KS>
+template <int BCO, int BCI, int KS, int NW>
 void launch_wgrad_ks(WgradArgs a, hipStream_t stream, int force_splits, float* slab,
                      int split_target) {
     a.tiles_co = a.Cout / BCO;
@@ -274,21 +280,31 @@ void launch_wgrad_ks(WgradArgs a, hipStream_t stream, int force_splits, float* s
     constexpr int lds = 2 * KS * ((BCO * 2 + 64) + (BCI * 2 + 64));
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<BCO, BCI, KS>,
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<BCO, BCI, KS, NW>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<BCO, BCI, KS>), dim3(tiles, sp.splits), dim3(256), lds,
-                       stream, a);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<BCO, BCI, KS, NW>), dim3(tiles, sp.splits),
+                       dim3(NW * 64), lds, stream, a);
 }
 
 int g_kstep = 64;       // pixels per K step of the per-tap kernel (tuning: 32)
+// waves per block of the per-tap kernel for tiles with a 128 side: alone on the GPU eight waves
+// are 10-17 % faster wherever a CU holds one block, and inside the training step they are worth
+// ~1 % together with the tuned splits below (tools/ab_waves.sh)
+int g_waves = 8;
 
 template <int BCO, int BCI>
 void launch_wgrad(WgradArgs a, hipStream_t stream, int force_splits, float* slab,
                   int split_target) {
-    if (g_kstep == 32) launch_wgrad_ks<BCO, BCI, 32>(a, stream, force_splits, slab, split_target);
-    else launch_wgrad_ks<BCO, BCI, 64>(a, stream, force_splits, slab, split_target);
+    if constexpr (BCO == 128 || BCI == 128) {
+        if (g_waves == 8 && g_kstep == 64) {
+            launch_wgrad_ks<BCO, BCI, 64, 8>(a, stream, force_splits, slab, split_target);
+            return;
+        }
+    }
+    if (g_kstep == 32) launch_wgrad_ks<BCO, BCI, 32, 4>(a, stream, force_splits, slab, split_target);
+    else launch_wgrad_ks<BCO, BCI, 64, 4>(a, stream, force_splits, slab, split_target);
 }
 
 }  // namespace
@@ -326,6 +342,10 @@ void set_wgrad_kstep(int pixels) {
     if (pixels != 32 && pixels != 64) throw std::invalid_argument("set_wgrad_kstep: 32 or 64");
     g_kstep = pixels;
 }
+void set_wgrad_waves(int waves) {
+    if (waves != 4 && waves != 8) throw std::invalid_argument("set_wgrad_waves: 4 or 8");
+    g_waves = waves;
+}
 void set_wgrad_block_target(int blocks) {
     if (blocks < 0) throw std::invalid_argument("set_wgrad_block_target: negative");
     g_target = blocks;
@@ -336,6 +356,29 @@ int conv3x3_wgrad_splits(ConvShape s, int split_target) {
     if (use_tap_resident(s))
         return conv3x3_wgrad9_splits(s, conv3x3_wgrad9_bco(s, g_bco), 0, split_target);
     return plan_splits(s.batch * s.hw * s.hw, wgrad_tiles(s), 0, true, split_target).splits;
+}
+
+// Pixel splits tuned INSIDE the training step (tools/tune_wgrad_splits.py: coordinate descent over
+// the seven layers of VGG-11 at batch 256 on an MI355X, one bench run per candidate).  In the
+// two-stream backward the side stream's chain of weight-gradient kernels sets the pace, each of
+// them sharing the CUs with whatever the main chain runs at that moment, and the best split count
+// per layer is not a function of the block count alone: the tuned lists give 0.638 against
+// 0.653 ms/step with BatchNorm and 0.557 against 0.564 ms without.  0: no entry for this shape.
+int conv3x3_wgrad_tuned_splits(ConvShape s, bool batch_norm) {
+    if (s.batch != 256) return 0;
+    struct Entry { int hw, cin, cout, bn, plain; };
+    static const Entry table[] = {
+        {16, 64, 128, 40, 36}, {8, 128, 256, 10, 12}, {8, 256, 256, 10, 12},
+        {4, 256, 512, 2, 6},   {4, 512, 512, 3, 2},   {2, 512, 512, 1, 1},
+    };
+    for (const Entry& e : table)
+        if (e.hw == s.hw && e.cin == s.cin && e.cout == s.cout) return batch_norm ? e.bn : e.plain;
+    return 0;
+}
+
+// the split count a forced value turns into (whole 64-pixel steps per split)
+int conv3x3_wgrad_forced_splits(ConvShape s, int force_splits) {
+    return plan_splits(s.batch * s.hw * s.hw, wgrad_tiles(s), force_splits, true, 0).splits;
 }
 
 int conv3x3_wgrad_max_splits(ConvShape s) {

@@ -58,6 +58,8 @@ class NativeBackend:
             C.set_wgrad_block_target(int(os.environ["DML_WGRAD_TARGET"]))
         if os.environ.get("DML_WGRAD_KSTEP"):
             C.set_wgrad_kstep(int(os.environ["DML_WGRAD_KSTEP"]))
+        if os.environ.get("DML_WGRAD_WAVES"):
+            C.set_wgrad_waves(int(os.environ["DML_WGRAD_WAVES"]))
         self.engine = engine_cls(widths, cfg.batch_size, cfg.batch_norm, cfg.num_classes)
         e = self.engine
         f32 = dict(dtype=torch.float32, device=device)

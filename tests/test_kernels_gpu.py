@@ -260,18 +260,24 @@ def test_conv3x3_wgrad_tap_resident(hw, cin, cout, batch, bco, stages):
 @pytest.mark.parametrize("hw,cin,cout,batch", [
     (2, 512, 512, 256), (4, 256, 512, 256), (8, 128, 256, 256), (8, 256, 256, 7), (16, 64, 128, 64),
     (16, 128, 64, 2), (32, 64, 64, 16), (4, 64, 128, 3)])
-def test_conv3x3_wgrad_per_tap_short_k_step(hw, cin, cout, batch):
-    """The per-tap kernel with 32-pixel K steps (half the LDS per block): same numbers."""
+@pytest.mark.parametrize("variant", ["kstep32", "waves4"])
+def test_conv3x3_wgrad_per_tap_tuning_variants(hw, cin, cout, batch, variant):
+    """The per-tap kernel with 32-pixel K steps (half the LDS per block) and with four waves per
+    block instead of the default eight: same numbers."""
     n = native()
     x = rand_bf16(batch, hw, hw, cin, seed=91)
     dy = rand_bf16(batch, hw, hw, cout, seed=92)
     ref = torch.nn.grad.conv2d_weight(nchw(x), (cout, cin, 3, 3), nchw(dy), padding=1)
-    n.lib().set_wgrad_kstep(32)
+    if variant == "kstep32":
+        n.lib().set_wgrad_kstep(32)
+    else:
+        n.lib().set_wgrad_waves(4)
     try:
         dw = n.conv3x3_wgrad_per_tap(x, dy)
     finally:
         n.lib().set_wgrad_kstep(64)
-    check(f"wgrad ks32 {cin}->{cout}@{hw} B{batch}", dw.permute(0, 3, 1, 2), ref, rtol=2e-3,
+        n.lib().set_wgrad_waves(8)
+    check(f"wgrad {variant} {cin}->{cout}@{hw} B{batch}", dw.permute(0, 3, 1, 2), ref, rtol=2e-3,
           atol_scale=2e-3)
 
 
