@@ -213,6 +213,19 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
             if (*q == ',') ++q;
         }
     }
+    dgrad_force_plan_.assign(convs_.size(), std::array<int, 5>{0, 0, 0, -1, 0});
+    if (const char* e = getenv("DML_DGRAD_PLANS")) {   // tuning: "bm:bn:splits:pm:waves,..." for layers 1..
+        size_t i = 1;
+        for (const char* q = e; *q && i < convs_.size(); ++i) {
+            int k = 0;
+            while (*q && *q != ',') {
+                if (k < 5) dgrad_force_plan_[i][k++] = atoi(q);
+                while (*q && *q != ':' && *q != ',') ++q;
+                if (*q == ':') ++q;
+            }
+            if (*q == ',') ++q;
+        }
+    }
     for (size_t i = 0; i < convs_.size(); ++i) {
         Conv& c = convs_[i];
         c.wslab_off = w;
@@ -641,7 +654,8 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             }
             conv3x3_igemm(g, arena_ + c.wd_off, arriving(i - 1), nullptr,
                           fold_relu ? arena_ + prev.out_off : nullptr, slab, slab_elems_, d,
-                          fold_relu ? EPI_MASK : EPI_NONE, stream, nullptr, nullptr,
+                          fold_relu ? EPI_MASK : EPI_NONE, stream,
+                          dgrad_force_plan_[i][0] > 0 ? dgrad_force_plan_[i].data() : nullptr, nullptr,
                           defer_sum ? &pending : nullptr, want_sums ? &red : nullptr,
                           want_sums ? &bn_sums : nullptr);
         }

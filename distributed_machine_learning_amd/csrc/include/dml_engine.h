@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <array>
 #include <vector>
 
 #include "dml_comm.h"
@@ -201,6 +202,8 @@ class VggEngine {
     hipEvent_t side_done_ = nullptr;
     std::vector<int> wgrad_queue_;          // layers whose gradient is ready, wgrad not yet launched
     bool tuned_wgrad_splits_ = true;        // use conv3x3_wgrad_tuned_splits where it has an entry
+    // tuning (DML_DGRAD_PLANS): backward-data plan {bm, bn, splits, pm, waves} per conv layer, bm 0 = default
+    std::vector<std::array<int, 5>> dgrad_force_plan_;
     std::vector<int> wgrad_force_splits_;   // tuning (DML_WGRAD_SPLITS): pixel splits per conv layer, 0 = planned
     bool side_done_recorded_ = false;
     bool side_busy_ = false;                // side-stream work the main stream has not waited for
