@@ -16,6 +16,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <cstdlib>
 #include <stdexcept>
 
 #include "dml_engine.h"
@@ -70,6 +71,15 @@ VggEngineF32::VggEngineF32(const std::vector<int>& widths, int max_batch, bool b
     tb_off_ = a; a = align_up(a + max_act);
     arena_elems_ = a;
 
+    wgrad_force_splits_.assign(lay_.convs.size(), 0);
+    if (const char* e = getenv("DML_WGRAD_F32_SPLITS")) {  // tuning: "s1,s2,..." for conv layers 1..
+        size_t i = 1;
+        for (const char* q = e; *q && i < lay_.convs.size(); ++i) {
+            wgrad_force_splits_[i] = atoi(q);
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
     size_t w = 0;
     logits_off_ = w; w = align_up(w + B * 16);
     loss_off_ = w;   w = align_up(w + 64);
@@ -82,7 +92,12 @@ VggEngineF32::VggEngineF32(const std::vector<int>& widths, int max_batch, bool b
         if (bn_) w = align_up(w + 2 * (size_t)c.cout);
         buf_[i].wslab_off = w;
         if (i > 0) {
-            const int splits = conv3x3_wgrad_f32_splits({max_batch_, c.hw, c.cin, c.cout});
+            const ConvShape full = {max_batch_, c.hw, c.cin, c.cout};
+            int splits = conv3x3_wgrad_f32_splits(full);
+            if (wgrad_force_splits_[i] > 0) {
+                const int f = conv3x3_wgrad_f32_splits(full, wgrad_force_splits_[i]);
+                splits = f > splits ? f : splits;
+            }
             if (splits > 1) w = align_up(w + (size_t)splits * c.cout * 9 * c.cin);
         }
     }
@@ -364,8 +379,9 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
             // (the reduction scratch is free: BatchNorm, its other user, is off in this case)
             if (!bn_) column_sum(g, grads_ + c.b_off, rows, c.cout, ws_ + stats_off_, wstream);
             const ConvShape s = {batch, c.hw, c.cin, c.cout};
-            conv3x3_wgrad_f32(in, g, grads_ + c.w_off, s, ws_ + b.wslab_off, wstream);
-            const int splits = conv3x3_wgrad_f32_splits(s);
+            const int forced = wgrad_force_splits_[i];
+            conv3x3_wgrad_f32(in, g, grads_ + c.w_off, s, ws_ + b.wslab_off, wstream, forced);
+            const int splits = conv3x3_wgrad_f32_splits(s, forced);
             if (splits > 1) {
                 if (sums_.n == SlabSumJobs::kMax) flush_sums(wstream);
                 const int j = sums_.n++;

@@ -294,6 +294,7 @@ class VggEngineF32 {
     // Outputs of the tap-split convolutions (two blocks per position meet through atomics, so the
     // output starts at zero): all of a step's are cleared by one launch at the start of forward -
     // on the side stream when there is one - instead of a memset in front of each convolution.
+    std::vector<int> wgrad_force_splits_;   // tuning (DML_WGRAD_F32_SPLITS): pixel splits per conv layer, 0 = planned
     std::vector<char> fwd_cleared_, bwd_cleared_;   // per layer: forward / backward-data output
     hipEvent_t fwd_begin_ = nullptr, cleared_ = nullptr;
     bool clear_pending_ = false;

@@ -2,6 +2,7 @@
 full training step (DML_WGRAD_SPLITS), one bench.py run per candidate.
 
     python tools/tune_wgrad_splits.py [bench args...]
+    KNOB=DML_WGRAD_F32_SPLITS START=57,29,15,22,11,11,11 python tools/tune_wgrad_splits.py --dtype fp32
 """
 import json
 import os
@@ -13,7 +14,8 @@ ARGS = sys.argv[1:]
 
 
 def run(splits, waves):
-    env = dict(os.environ, DML_WGRAD_SPLITS=",".join(map(str, splits)), DML_WGRAD_WAVES=str(waves))
+    env = dict(os.environ, DML_WGRAD_WAVES=str(waves))
+    env[os.environ.get("KNOB", "DML_WGRAD_SPLITS")] = ",".join(map(str, splits))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup",
                           "30", "--windows", "3"] + ARGS, capture_output=True, text=True, env=env,
                          timeout=200)
@@ -39,7 +41,7 @@ def main():
                 trial[layer] = c
                 t = run(trial, waves)
                 mark = ""
-                if t < best_t - 0.0015:
+                if t < best_t - float(os.environ.get("THRESH", "0.0015")):
                     best, best_t, mark = trial, t, "  <- better"
                 print(f"round {rnd} layer {layer + 1} splits {c:3d}: {t:.4f} ms{mark}", flush=True)
         print(f"after round {rnd}: {best} -> {best_t:.4f} ms", flush=True)
