@@ -213,6 +213,17 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
             if (*q == ',') ++q;
         }
     }
+    wgrad_resident_.assign(convs_.size(), std::array<int, 2>{0, 0});
+    if (const char* e = getenv("DML_WGRAD_RESIDENT")) {     // tuning: "bco:stages,..." for layers 1..
+        size_t i = 1;
+        for (const char* q = e; *q && i < convs_.size(); ++i) {
+            wgrad_resident_[i][0] = atoi(q);
+            while (*q && *q != ':' && *q != ',') ++q;
+            if (*q == ':') { ++q; wgrad_resident_[i][1] = atoi(q); }
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
     dgrad_force_plan_.assign(convs_.size(), std::array<int, 5>{0, 0, 0, -1, 0});
     if (const char* e = getenv("DML_DGRAD_PLANS")) {   // tuning: "bm:bn:splits:pm:waves,..." for layers 1..
         size_t i = 1;
@@ -234,6 +245,10 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         const ConvShape ws_shape = {max_batch_, c.hw, c.cin, c.cout};
         int splits = conv3x3_wgrad_max_splits(ws_shape);
         if (wgrad_force_splits_[i] > splits) splits = wgrad_force_splits_[i];
+        if (wgrad_resident_[i][0] > 0) {
+            const int r = conv3x3_wgrad9_splits(ws_shape, wgrad_resident_[i][0], wgrad_force_splits_[i]);
+            splits = r > splits ? r : splits;
+        }
         const int tuned = conv3x3_wgrad_tuned_splits({256, c.hw, c.cin, c.cout}, bn_);
         if (max_batch_ >= 256 && tuned > splits) splits = tuned;
         if (splits > 1) w = align_up(w + (size_t)splits * c.cout * 9 * c.cin);
@@ -338,6 +353,21 @@ void VggEngine::launch_wgrad(int i, int batch, hipStream_t stream) {
     // pixel splits: the tuning override, else the list tuned inside the step for this shape, else
     // the kernel's plan for the block target
     int forced = wgrad_force_splits_[i];
+    if (wgrad_resident_[i][0] > 0) {        // tuning: the tap-resident kernel for this layer
+        const int bco = wgrad_resident_[i][0];
+        const int n = conv3x3_wgrad9_splits(s, bco, forced, wgrad_split_target());
+        conv3x3_wgrad9(in, g, grads_ + c.w_off, s, stream, ws_ + c.wslab_off, bco, n,
+                       wgrad_resident_[i][1] == 3 ? 3 : 2);
+        if (n > 1) {
+            if (wgrad_sums_.n == SlabSumJobs::kMax) flush_wgrad_sums(stream);
+            const int j = wgrad_sums_.n++;
+            wgrad_sums_.src_off[j] = c.wslab_off;
+            wgrad_sums_.dst_off[j] = c.w_off;
+            wgrad_sums_.count[j] = (size_t)c.cout * 9 * c.cin;
+            wgrad_sums_.splits[j] = n;
+        }
+        return;
+    }
     if (forced == 0 && tuned_wgrad_splits_) forced = conv3x3_wgrad_tuned_splits(s, bn_);
     conv3x3_wgrad(in, g, grads_ + c.w_off, s, stream, forced, ws_ + c.wslab_off, target);
     const int splits = forced > 0 ? conv3x3_wgrad_forced_splits(s, forced)

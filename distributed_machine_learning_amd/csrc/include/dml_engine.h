@@ -205,6 +205,9 @@ class VggEngine {
     // tuning (DML_DGRAD_PLANS): backward-data plan {bm, bn, splits, pm, waves} per conv layer, bm 0 = default
     std::vector<std::array<int, 5>> dgrad_force_plan_;
     std::vector<int> wgrad_force_splits_;   // tuning (DML_WGRAD_SPLITS): pixel splits per conv layer, 0 = planned
+    // tuning (DML_WGRAD_RESIDENT): "bco:stages" per conv layer to run the tap-resident kernel there
+    // (with the layer's DML_WGRAD_SPLITS entry as its split count), "0" for the per-tap kernel
+    std::vector<std::array<int, 2>> wgrad_resident_;
     bool side_done_recorded_ = false;
     bool side_busy_ = false;                // side-stream work the main stream has not waited for
     hipGraph_t graph_ = nullptr;
