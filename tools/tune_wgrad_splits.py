@@ -34,8 +34,13 @@ def main():
     for rnd in range(2):
         for layer in (4, 3, 2, 1, 0, 5, 6):
             cur = best[layer]
-            cands = sorted({max(1, cur // 2), max(1, cur * 3 // 4), cur + max(1, cur // 4),
-                            cur + max(1, cur // 2), cur * 2} - {cur})
+            if os.environ.get("FINE"):      # neighbours of a list that is already tuned
+                step = max(1, cur // 10)
+                cands = sorted({max(1, cur - 2 * step), max(1, cur - step), cur + step,
+                                cur + 2 * step} - {cur})
+            else:
+                cands = sorted({max(1, cur // 2), max(1, cur * 3 // 4), cur + max(1, cur // 4),
+                                cur + max(1, cur // 2), cur * 2} - {cur})
             for c in cands:
                 trial = list(best)
                 trial[layer] = c
