@@ -51,6 +51,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prime-steps", type=int, default=100,
+                    help="set-up, before the warm-up steps: this many steps on a snapshot of the "
+                         "training state (restored afterwards), so that code objects are loaded "
+                         "and the GPU is at its steady clocks whatever --warmup is")
     ap.add_argument("--mode", choices=tuple(MODE_SYNC), default="part3")
     ap.add_argument("--batch-size", type=int, default=256, help="images per GPU")
     bn = ap.add_mutually_exclusive_group()
@@ -282,6 +286,10 @@ def run_rank(ns) -> None:
             backend.comm_only_step()
         barrier()
 
+    if ns.prime_steps > 0 and hasattr(backend, "prime"):
+        backend.prime(batches, ns.prime_steps)
+        barrier()
+
     loss = None
     for i in range(ns.warmup):
         loss = backend.train_step(*batches[i % len(batches)])
@@ -346,7 +354,8 @@ def run_rank(ns) -> None:
                        "mode": ns.mode, "sync": sync, "global_batch": ns.batch_size * world,
                        "batch_per_gpu": ns.batch_size, "image": "3x32x32", "parallelism": par,
                        "optimizer": "SGD lr0.1 m0.9 wd1e-4 (fused)", "backend": backend.name,
-                       "graph": bool(ns.graph), "bucket_cap_mb": ns.bucket_cap_mb,
+                       "graph": bool(ns.graph), "prime_steps": ns.prime_steps,
+                       "bucket_cap_mb": ns.bucket_cap_mb,
                        "tail_bucket_cap_mb": ns.tail_bucket_cap_mb,
                        "sync_plan": backend.sync_plan() if hasattr(backend, "sync_plan") else None,
                        "host_enqueue_ms_per_step": round(host_elapsed / probe * 1e3, 4),

@@ -391,6 +391,29 @@ class NativeBackend:
         self.momentum.zero_()
         self.engine.refresh_weights(self._stream())
 
+    @torch.no_grad()
+    def prime(self, batches, steps: int) -> None:
+        """Run ``steps`` training steps and put every piece of training state back afterwards
+        (master weights, momentum, running statistics and their step count): code objects are
+        loaded, RCCL channels and caches are warm and the GPU has reached its steady clocks
+        before anything is measured, and the trajectory is the one of an unprimed run.  With
+        more than one rank every rank must call it with the same ``steps``."""
+        if steps <= 0:
+            return
+        keep = (self.params.clone(), self.momentum.clone(), self.bn_buffers.clone(),
+                int(self.engine.bn_steps))
+        for i in range(steps):
+            self.train_step(*batches[i % len(batches)])
+        torch.cuda.current_stream().synchronize()
+        self.params.copy_(keep[0])
+        self.momentum.copy_(keep[1])
+        self.bn_buffers.copy_(keep[2])
+        self.engine.bn_steps = keep[3]
+        if getattr(self, "reducer", None) is not None:
+            self.reducer.drop_pending_buffers()
+        self.engine.refresh_weights(self._stream())
+        torch.cuda.current_stream().synchronize()
+
     def parameters_flat(self) -> torch.Tensor:
         return self.params
 

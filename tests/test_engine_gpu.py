@@ -383,6 +383,34 @@ def test_wgrad_side_stream_matches_single_stream(batch_norm, mode):
             comm.destroy()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_priming_leaves_the_trajectory_alone(dtype):
+    """Backend.prime() (bench.py's set-up steps) puts weights, momentum, running statistics and
+    their step count back: the steps after it give the bits of an unprimed run."""
+    from distributed_machine_learning_amd.config import TrainConfig
+    from distributed_machine_learning_amd.engine.native_backend import NativeBackend
+    from distributed_machine_learning_amd.models import VGG
+    torch.manual_seed(4321)
+    state = VGG("VGG11", True).to(DEV).state_dict()
+    runs = []
+    for primed in (False, True):
+        cfg = TrainConfig(batch_size=32, batch_norm=True, sync="none", dtype=dtype, backend="native",
+                          lr=0.05)
+        nb = NativeBackend(cfg, DEV, None, init_state=state)
+        batches = []
+        for seed in range(3):
+            _, x4, t = _batch(32, seed=seed)
+            batches.append((x4.float().contiguous() if dtype == "fp32" else x4, t))
+        if primed:
+            nb.prime(batches, 7)
+        losses = [nb.train_step(*batches[i % 3]).clone() for i in range(4)]
+        runs.append((torch.stack(losses), nb.params.clone(), nb.momentum.clone(),
+                     nb.bn_buffers.clone(), int(nb.engine.bn_steps)))
+    a, b = runs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(a[3], b[3]) and a[4] == b[4] == 4
+
+
 def test_side_streams_sit_on_their_own_hardware_queues():
     """HIP shares a few hardware queues among all streams, and streams on one queue run in
     line: the communication stream and the weight-gradient stream are probed at creation, so
