@@ -617,6 +617,8 @@ DML_IGEMM_INSTANTIATE(128, 128, 3, false, 8)
 DML_IGEMM_INSTANTIATE(128, 128, 4, false, 8)
 DML_IGEMM_INSTANTIATE(128, 128, 3, true, 8)
 DML_IGEMM_INSTANTIATE(128, 128, 4, true, 8)
+DML_IGEMM_INSTANTIATE(128, 128, 2, false, 8)
+DML_IGEMM_INSTANTIATE(128, 128, 2, true, 8)
 #undef DML_IGEMM_INSTANTIATE
 
 // Sums the per-split fp32 slabs and applies the epilogue; 4 outputs per thread.
@@ -700,6 +702,7 @@ struct Plan {
     int bm, bn, splits;
     bool pm;
     int waves;      // 4, 8 (3 LDS stages), 9 = eight waves with 4 LDS stages (tuning),
+                    // 10 = eight waves with 2 LDS stages (64 KiB: two blocks per CU),
                     // 16 = patch-resident kernel (eight waves for 128-row tiles, four for 64)
 };
 
@@ -721,11 +724,14 @@ Plan choose_plan(int batch, int hw, int N, const int* force = nullptr) {
         return {force[0], force[1], force[2] > 0 ? force[2] : 1, pm, force[4] > 0 ? force[4] : 4};
     }
     auto blocks = [&](int bm, int bn) { return (N % bn) ? 0 : ((M + bm - 1) / bm) * (N / bn); };
-    if (blocks(128, 128) >= 256) return {128, 128, 1, false, 8};
+    // (two LDS stages and two blocks per CU beat three stages and one: a second block's main
+    // loop covers the first one's prologue and epilogue, which are a third of a block's life at
+    // 9-36 K steps - 64 -> 128 @ 16x16 forward 17.9 -> 14.6 us, 256 -> 256 @ 8x8 24.0 -> 22.1 us)
+    if (blocks(128, 128) >= 256) return {128, 128, 1, false, 10};
     if (blocks(128, 64) >= 512) return {128, 64, 1, false, 4};
     const int b = blocks(64, 64);
     if (b > 256) return {64, 64, 1, false, 16};     // patch-resident: 5-12 % faster at this size
-    if (blocks(128, 128) * 3 >= 192) return {128, 128, 3, pm_ok(128), 9};
+    if (blocks(128, 128) * 3 >= 192) return {128, 128, 3, pm_ok(128), 10};
     if (b >= 256) return {64, 64, 1, false, 4};
     if (b * 3 >= 128) return {64, 64, 3, pm_ok(64), 4};
     return {64, 64, 9, pm_ok(64), 4};
@@ -1117,7 +1123,12 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
     a.M = s.batch * s.hw * s.hw; a.N = s.cout; a.C = s.cin;
     a.hw = s.hw; a.log_hw = ilog2(s.hw); a.log_chunks = ilog2(s.cin / 64);
     a.batch = s.batch; a.img_blocks = 0;
-    const Plan pl = choose_plan(s.batch, s.hw, a.N, force_plan);
+    Plan pl = choose_plan(s.batch, s.hw, a.N, force_plan);
+    // The two-stage form is a forward choice: backward-data runs next to the weight-gradient
+    // kernels of the side stream, and there one block per CU with a deeper ring measures better
+    // inside the step (0.637 against 0.648 ms) although two blocks per CU win stand-alone.
+    if (!force_plan && pl.waves == 10 && (epi == EPI_NONE || epi == EPI_MASK))
+        pl.waves = pl.splits > 1 ? 9 : 8;
     if (!((pl.bm == 128 || pl.bm == 64) && (pl.bn == 128 || pl.bn == 64) && a.N % pl.bn == 0 &&
           (pl.splits == 1 || pl.splits == 3 || pl.splits == 9)) || (pl.bm == 64 && pl.bn == 128))
         throw std::invalid_argument("conv3x3_igemm: unsupported tile plan");
@@ -1150,6 +1161,8 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
         launch_layout<128, 128, 2, 3, 8>(a, epi, pl.splits, pl.pm, stream);
     else if (pl.bm == 128 && pl.bn == 128 && pl.waves == 9)
         launch_layout<128, 128, 2, 4, 8>(a, epi, pl.splits, pl.pm, stream);
+    else if (pl.bm == 128 && pl.bn == 128 && pl.waves == 10)    // two LDS stages: two blocks per CU
+        launch_layout<128, 128, 2, 2, 8>(a, epi, pl.splits, pl.pm, stream);
     else if (pl.bm == 128 && pl.bn == 128)
         launch_layout<128, 128, 2, 3, 4>(a, epi, pl.splits, pl.pm, stream);
     else if (pl.bm == 128 && pl.bn == 64)

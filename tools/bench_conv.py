@@ -48,7 +48,7 @@ def main():
         ws = torch.empty(9 * M * max(cin, cout), device=DEV)
         plans = [(128, 128, 1), (128, 64, 1), (64, 64, 1), (128, 128, 3), (128, 64, 3), (64, 64, 3),
                  (64, 64, 9), (0, 0, 0)]
-        waves_opts = (4, 8, 9, 16)
+        waves_opts = (4, 8, 9, 10, 16)
         for kind in which:
             if kind == "wgrad":
                 C.set_wgrad_variant(1)      # the one-tap-per-block kernel
@@ -81,7 +81,7 @@ def main():
                             del slab
                 continue
             for (bm, bn, sp), pm, nw in itertools.product(plans, (0, 1), waves_opts):
-                if nw in (8, 9) and (bm, bn) != (128, 128):
+                if nw in (8, 9, 10) and (bm, bn) != (128, 128):
                     continue
                 if nw == 16 and (sp != 1 or pm or bm == 0):
                     continue

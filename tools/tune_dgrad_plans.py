@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 ARGS = sys.argv[1:]
-CANDS = ["128:128:1:0:8", "128:128:1:0:9", "128:128:1:0:4", "128:64:1:0:4", "64:64:1:0:4",
+CANDS = ["128:128:1:0:8", "128:128:1:0:9", "128:128:1:0:10", "128:128:3:-1:10", "128:128:1:0:4", "128:64:1:0:4", "64:64:1:0:4",
          "64:64:1:0:16", "128:64:1:0:16", "128:128:1:0:16", "128:128:3:-1:9", "128:128:3:-1:8",
          "64:64:3:-1:4", "64:64:9:-1:4", "128:64:3:-1:4"]
 
