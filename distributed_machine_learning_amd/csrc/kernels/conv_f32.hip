@@ -143,9 +143,13 @@ void conv3x3_igemm_f32_kernel(IgemmParams p) {
     // Staging registers of the chunk after the one being multiplied.  Loads are branch-free
     // (a row outside the map or the tensor reads a safe address and is zeroed) and issued
     // unconditionally - the last iteration re-loads the last chunk and nobody reads it.
-    f32x4 ra[LA], rb[LB];
+    // Two sets of them, used alternately: the loads of chunk s + 2 are issued at the top of chunk
+    // s and written to LDS at the bottom of chunk s + 1, so they have two chunks of MFMAs (~2000
+    // cycles for a 64 x 64 tile) to land instead of one - under load a global load takes longer
+    // than one chunk.
+    f32x4 ra0[LA], rb0[LB], ra1[LA], rb1[LB];
     int ld_tap = 0, ld_chunk = 0;           // position of the next chunk to load
-#define DML_F32_FETCH()                                                                        \
+#define DML_F32_FETCH(ra, rb)                                                                  \
     {                                                                                          \
         const int ti = ld_tap < ntaps ? ld_tap : ntaps - 1;                                    \
         const int tap = (int)((taps >> (4 * ti)) & 15);                                        \
@@ -162,7 +166,7 @@ void conv3x3_igemm_f32_kernel(IgemmParams p) {
             rb[i] = *(const f32x4*)(p.w + b_base[i] + (long)tap * cin + c0);                   \
         if (++ld_chunk == chunks) { ld_chunk = 0; ++ld_tap; }                                  \
     }
-#define DML_F32_STASH(buf)                                                                     \
+#define DML_F32_STASH(buf, ra, rb)                                                             \
     {                                                                                          \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                       \
             const int idx = tid + 256 * i, row = idx >> 3, slot = (idx & 7) ^ (row & 7);       \
@@ -185,35 +189,43 @@ void conv3x3_igemm_f32_kernel(IgemmParams p) {
         }                                                                                      \
     }
 
-    DML_F32_FETCH();
-    DML_F32_STASH(0);
+    // Operand fragments one group ahead of the MFMAs that use them.  The scheduling barriers pin
+    // that order: left alone, hipcc sinks the global loads to the end of the chunk and reads each
+    // fragment right before its first use, exposing both latencies on every group.
+#define DML_F32_CHUNK(buf)                                                                     \
+    {                                                                                          \
+        f32x4 fa[2][MT], fb[2][NT];                                                            \
+        DML_F32_FRAGS(buf, 0, fa[0], fb[0]);                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                        \
+            if (q < 3) DML_F32_FRAGS(buf, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);            \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                      \
+                _Pragma("unroll") for (int a = 0; a < MT; ++a)                                 \
+                    _Pragma("unroll") for (int b = 0; b < NT; ++b)                             \
+                        acc[a][b] = mfma32(fa[q & 1][a][t], fb[q & 1][b][t], acc[a][b]);       \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+        }                                                                                      \
+    }
+
+    DML_F32_FETCH(ra0, rb0);                // chunk 0
+    DML_F32_STASH(0, ra0, rb0);
+    DML_F32_FETCH(ra1, rb1);                // chunk 1
     __syncthreads();
-    for (int step = 0; step < steps; ++step) {
-        const int buf = step & 1;
-        DML_F32_FETCH();                    // in flight behind this chunk's MFMAs
-        // Operand fragments one group ahead of the MFMAs that use them.  The scheduling
-        // barriers pin that order: left alone, hipcc sinks the global loads to the end of the
-        // chunk and reads each fragment right before its first use, exposing both latencies
-        // on every group (one wave per SIMD has nothing else to run meanwhile).
-        f32x4 fa[2][MT], fb[2][NT];
-        DML_F32_FRAGS(buf, 0, fa[0], fb[0]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q < 3) DML_F32_FRAGS(buf, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int a = 0; a < MT; ++a)
-#pragma unroll
-                    for (int b = 0; b < NT; ++b)
-                        acc[a][b] = mfma32(fa[q & 1][a][t], fb[q & 1][b][t], acc[a][b]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        DML_F32_STASH(buf ^ 1);
+    // chunk `step` is in LDS buffer step & 1; chunk step + 1 is in flight in set (step + 1) & 1
+    int step = 0;
+    for (; step + 1 < steps; step += 2) {
+        DML_F32_FETCH(ra0, rb0);            // chunk step + 2
+        DML_F32_CHUNK(0);
+        DML_F32_STASH(1, ra1, rb1);         // chunk step + 1
+        __syncthreads();
+        DML_F32_FETCH(ra1, rb1);            // chunk step + 3
+        DML_F32_CHUNK(1);
+        DML_F32_STASH(0, ra0, rb0);         // chunk step + 2
         __syncthreads();
     }
+    if (step < steps) DML_F32_CHUNK(0);     // odd count: the last chunk sits in buffer 0
+#undef DML_F32_CHUNK
 #undef DML_F32_FETCH
 #undef DML_F32_STASH
 #undef DML_F32_FRAGS
