@@ -184,9 +184,20 @@ def run_rank(ns) -> None:
     if world != ns.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {ns.gpus}")
     if ns.dry_launch:
+        # the bootstrap exchange of the real run (rank 0 publishes the communicator's id, the
+        # others fetch it) with a stand-in id, through the store the real run would use
+        boot = None
+        if world > 1:
+            import hashlib
+            from distributed_machine_learning_amd.parallel.comm import exchange_bootstrap_bytes
+            blob, _store = exchange_bootstrap_bytes(master, rank, world, 60.0,
+                                                    lambda: os.urandom(128), key="dml_dry_launch_id")
+            boot = hashlib.sha256(blob).hexdigest()[:16]
         # one write per line: the ranks share the parent's stdout
         os.write(1, (json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank,
-                                 "world_size": world, "master": master,
+                                 "world_size": world, "master": master, "bootstrap_id": boot,
+                                 "agent_store": os.environ.get("TORCHELASTIC_USE_AGENT_STORE",
+                                                               "").lower() == "true",
                                  "self_launched": os.environ.get("DML_BENCH_SELF_LAUNCHED") == "1"})
                      + "\n").encode())
         return

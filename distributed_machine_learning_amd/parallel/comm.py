@@ -85,6 +85,42 @@ class _Done:
         return None
 
 
+def exchange_bootstrap_bytes(master_ip: str, rank: int, world_size: int, timeout_s: float,
+                             make, key: str = "dml_rccl_unique_id"):
+    """Rank 0 calls ``make()`` and publishes the bytes; everyone else fetches them.
+    Returns ``(bytes, store)``; the caller keeps ``store`` (the native one, or None) alive.
+
+    Stand-alone launches (one process per rank started by hand, by ``launch.py`` or by
+    ``bench.py`` itself, like the reference) use the native TCP store listening on
+    ``master_ip``.  Under ``torchrun`` that port already belongs to the launcher's
+    own rendezvous store, which hands workers a client connection; the id is
+    published there instead of opening a second listener on a guessed port.
+    """
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true":
+        from torch.distributed import TCPStore
+        store = TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]),
+                         world_size, is_master=False,
+                         timeout=datetime.timedelta(seconds=timeout_s))
+        key += "_" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+        if rank == 0:
+            blob = bytes(make())
+            store.set(key, blob)
+        else:
+            blob = bytes(store.get(key))
+        return blob, None
+    from ..ops import native
+    host, port = split_host_port(master_ip)
+    store = native.lib().TcpStore(host, port, rank == 0, world_size, float(timeout_s))
+    if rank == 0:
+        blob = bytes(make())
+        store.set(key, blob)
+    else:
+        blob = bytes(store.get(key))
+    # nobody may tear the server down before every rank has read the id
+    store.barrier("uid_read")
+    return blob, store
+
+
 class RcclCommunicator(Communicator):
     """Native communicator for device tensors (RCCL; ``transport="loopback"`` for tests).
 
@@ -120,36 +156,8 @@ class RcclCommunicator(Communicator):
 
     # -- bootstrap ---------------------------------------------------------------
     def _exchange_unique_id(self, master_ip, rank, world_size, timeout_s) -> bytes:
-        """Rank 0 creates the id and publishes it; everyone else fetches it.
-
-        Stand-alone launches (one process per rank started by hand, by ``launch.py`` or by
-        ``bench.py`` itself, like the reference) use the native TCP store listening on
-        ``master_ip``.  Under ``torchrun`` that port already belongs to the launcher's
-        own rendezvous store, which hands workers a client connection; the id is
-        published there instead of opening a second listener on a guessed port.
-        """
-        key = "dml_rccl_unique_id"
-        if os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true":
-            from torch.distributed import TCPStore
-            store = TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]),
-                             world_size, is_master=False,
-                             timeout=datetime.timedelta(seconds=timeout_s))
-            key += "_" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
-            if rank == 0:
-                uid = self._C.rccl_unique_id()
-                store.set(key, uid)
-            else:
-                uid = bytes(store.get(key))
-            return uid
-        host, port = split_host_port(master_ip)
-        self._store = self._C.TcpStore(host, port, rank == 0, world_size, float(timeout_s))
-        if rank == 0:
-            uid = self._C.rccl_unique_id()
-            self._store.set(key, uid)
-        else:
-            uid = self._store.get(key)
-        # nobody may tear the server down before every rank has read the id
-        self._store.barrier("uid_read")
+        uid, self._store = exchange_bootstrap_bytes(master_ip, rank, world_size, timeout_s,
+                                                    self._C.rccl_unique_id)
         return uid
 
     # -- helpers -----------------------------------------------------------------

@@ -69,6 +69,36 @@ def test_bench_self_launch_dry_run():
     assert [d["rank"] for d in recs] == [0, 1] and [d["local_rank"] for d in recs] == [0, 1]
     assert all(d["world_size"] == 2 and d["self_launched"] for d in recs)
     assert recs[0]["master"] == recs[1]["master"] and recs[0]["master"].startswith("127.0.0.1:")
+    # the communicator id rank 0 publishes through the native store reaches rank 1 unchanged
+    assert recs[0]["bootstrap_id"] and recs[0]["bootstrap_id"] == recs[1]["bootstrap_id"]
+    assert not recs[0]["agent_store"]
+
+
+def test_bench_under_torchrun_dry_run():
+    """The harness' multi-GPU command line: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.  Every rank
+    must take its rank triple from the launcher and exchange the communicator id through the
+    launcher's own store (MASTER_PORT is already bound by it)."""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4",
+                        "--steps", "3", "--warmup", "1", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr
+    recs = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")),
+                  key=lambda d: d["rank"])
+    assert [d["rank"] for d in recs] == [0, 1, 2, 3]
+    assert [d["local_rank"] for d in recs] == [0, 1, 2, 3]
+    assert all(d["world_size"] == 4 and not d["self_launched"] and d["agent_store"] for d in recs)
+    assert all(d["master"] == f"127.0.0.1:{port}" for d in recs)
+    assert recs[0]["bootstrap_id"] and len({d["bootstrap_id"] for d in recs}) == 1
 
 
 def test_bench_launcher_env_must_match_gpus():
