@@ -14,6 +14,7 @@
 //   join -> reducer.wait_all -> fused SGD -> weight shadow / repack  optimizer.step()
 #include "dml_engine.h"
 
+#include <cstring>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -265,6 +266,7 @@ VggEngine::~VggEngine() {
     if (grads_final_) (void)hipEventDestroy(grads_final_);
     if (late_done_) (void)hipEventDestroy(late_done_);
     if (wgrad_stream_) (void)hipStreamDestroy(wgrad_stream_);
+    if (hand_off_flags_) (void)hipFree(hand_off_flags_);
 }
 
 void VggEngine::set_wgrad_overlap(bool on, int group, hipStream_t compute_stream) {
@@ -276,11 +278,29 @@ void VggEngine::set_wgrad_overlap(bool on, int group, hipStream_t compute_stream
         if (reducer_ && reducer_->comm_stream()) avoid.push_back(reducer_->comm_stream());
         wgrad_stream_ = create_concurrent_stream(avoid);
         hand_off_.resize(convs_.size());
+        // These events order two queues of ONE GPU, and every kernel releases its writes to the
+        // whole device as it ends, so the events need no system-scope fence of their own
+        // (-1.6 % step time; DML_EVENT_SCOPE=system brings the default fence back).
+        unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
+        if (const char* e = getenv("DML_EVENT_SCOPE"))
+            if (!strcmp(e, "system")) flags = hipEventDisableTiming;
+        // Hand-offs main -> side through a flag word and a wait-value packet where the device
+        // supports it (DML_HANDOFF=event: the event pair instead).
+        int can_wait_value = 0, device = 0;
+        check_hip(hipGetDevice(&device), "hipGetDevice");
+        (void)hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device);
+        const char* mode = getenv("DML_HANDOFF");
+        value_hand_off_ = can_wait_value && !(mode && !strcmp(mode, "event"));
+        if (value_hand_off_) {
+            check_hip(hipMalloc((void**)&hand_off_flags_, convs_.size() * sizeof(unsigned)), "hipMalloc(hand-off flags)");
+            check_hip(hipMemset(hand_off_flags_, 0, convs_.size() * sizeof(unsigned)), "hipMemset(hand-off flags)");
+            check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(hand-off flags)");
+        }
         for (hipEvent_t& e : hand_off_)
-            check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-        check_hip(hipEventCreateWithFlags(&side_done_, hipEventDisableTiming), "hipEventCreate");
-        check_hip(hipEventCreateWithFlags(&grads_final_, hipEventDisableTiming), "hipEventCreate");
-        check_hip(hipEventCreateWithFlags(&late_done_, hipEventDisableTiming), "hipEventCreate");
+            check_hip(hipEventCreateWithFlags(&e, flags), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&side_done_, flags), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&grads_final_, flags), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&late_done_, flags), "hipEventCreate");
     }
     if ((on != wgrad_overlap_ || group != wgrad_group_) && graph_exec_) {
         (void)hipGraphExecDestroy(graph_exec_);     // a captured step has the old schedule
@@ -572,6 +592,9 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     wgrad_queue_.clear();       // (left-overs of a step that threw)
     wgrad_sums_.n = 0;
     side_done_recorded_ = false;
+    // (a captured graph keeps the event pair: its edges come from the capture)
+    const bool by_value = side && value_hand_off_ && !capturing_;
+    if (by_value) ++backward_seq_;
     const bool fuse_opt = side && opt_.on;
     opt_applied_ = fuse_opt;
     int updated_above = nconv + 1;      // layers >= this already had their parameters updated
@@ -656,8 +679,11 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             // (layer 0 finishes on the main stream: its weight gradient runs there, and a last
             // bucket that leaves from the main stream saves a cross-queue hop on the critical path)
             hand = i > 0 && (full || bucket_leaves(i));
-            if (hand) check_hip(hipEventRecord(hand_off_[i], stream), "hipEventRecord(hand-off)");
+            if (hand && !by_value)
+                check_hip(hipEventRecord(hand_off_[i], stream), "hipEventRecord(hand-off)");
         }
+        // by value: this layer's backward-data kernel, next in the main queue, raises the flag
+        const StreamSignal raise = {hand_off_flags_ ? hand_off_flags_ + i : nullptr, backward_seq_};
         if (i > 0) {
             // input gradient; the producer's ReLU is folded in when nothing sits in between
             const Conv& prev = convs_[i - 1];
@@ -687,10 +713,15 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                           fold_relu ? EPI_MASK : EPI_NONE, stream,
                           dgrad_force_plan_[i][0] > 0 ? dgrad_force_plan_[i].data() : nullptr, nullptr,
                           defer_sum ? &pending : nullptr, want_sums ? &red : nullptr,
-                          want_sums ? &bn_sums : nullptr);
+                          want_sums ? &bn_sums : nullptr, hand && by_value ? &raise : nullptr);
         }
         if (hand) {
-            check_hip(hipStreamWaitEvent(wgrad_stream_, hand_off_[i], 0), "hipStreamWaitEvent(hand-off)");
+            if (by_value)
+                check_hip(hipStreamWaitValue32(wgrad_stream_, hand_off_flags_ + i, backward_seq_,
+                                               hipStreamWaitValueGte, 0xffffffffu),
+                          "hipStreamWaitValue32(hand-off)");
+            else
+                check_hip(hipStreamWaitEvent(wgrad_stream_, hand_off_[i], 0), "hipStreamWaitEvent(hand-off)");
             if (fc_grads_pending) {
                 fc_grads(wgrad_stream_);
                 fc_grads_pending = false;

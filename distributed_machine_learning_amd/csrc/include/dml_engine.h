@@ -200,6 +200,11 @@ class VggEngine {
     int wgrad_group_ = 2;
     std::vector<hipEvent_t> hand_off_;      // per layer: main-stream position the side stream waits for
     hipEvent_t side_done_ = nullptr;
+    // hand-offs without a marker in the main queue (see StreamSignal): one flag word per layer,
+    // raised to the backward pass's sequence number by the layer's backward-data kernel
+    unsigned* hand_off_flags_ = nullptr;
+    unsigned backward_seq_ = 0;
+    bool value_hand_off_ = false;
     std::vector<int> wgrad_queue_;          // layers whose gradient is ready, wgrad not yet launched
     bool tuned_wgrad_splits_ = true;        // use conv3x3_wgrad_tuned_splits where it has an entry
     // tuning (DML_DGRAD_PLANS): backward-data plan {bm, bn, splits, pm, waves} per conv layer, bm 0 = default

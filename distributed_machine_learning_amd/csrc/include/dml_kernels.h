@@ -44,6 +44,18 @@ struct BnPartials {
     const float* shift = nullptr;
 };
 
+// A hand-off to another queue of the same GPU without a marker packet in the producing queue:
+// the kernel that FOLLOWS the producer stores `value` to `flag` (device memory) as its first
+// block starts - the queue runs its kernels in order, so everything before it has completed and
+// released its writes - and the consuming queue waits with hipStreamWaitValue32(flag >= value).
+// Measured on MI355X: an event record costs the producing queue 2-3 us per hand-off and the
+// consumer starts 8-10 us after the producer's end; this way the producing queue pays nothing
+// and the consumer starts after 3 us (tools/probes/waitvalue_probe.hip).
+struct StreamSignal {
+    unsigned* flag = nullptr;
+    unsigned value = 0;
+};
+
 // Partial results of a convolution that split its reduction: `splits` fp32 slabs of the
 // output, `stride` elements apart, still to be summed (splits == 0: nothing pending).
 struct SplitSlabs {
@@ -80,7 +92,8 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
                    ConvShape s, ConvEpilogue epi, hipStream_t stream,
                    const int* force_plan = nullptr /* tuning: {BM, BN, splits, position-major (-1 auto), waves} */,
                    float* stats = nullptr, SplitSlabs* defer = nullptr,
-                   const BnPoolReduce* bn_pool = nullptr, BnPartials* bn_done = nullptr);
+                   const BnPoolReduce* bn_pool = nullptr, BnPartials* bn_done = nullptr,
+                   const StreamSignal* signal = nullptr);
 size_t conv3x3_igemm_workspace_elems(ConvShape s);
 // With `stats` (EPI_BIAS, default plan) the kernel also leaves per-tile column sums and sums
 // of squares of the BIAS-FREE output: stats[row][0][n], stats[row][1][n] for

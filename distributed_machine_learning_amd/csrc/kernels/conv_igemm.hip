@@ -67,7 +67,16 @@ struct IgemmArgs {
     const uint16_t* bn_pre;
     const float *bn_gamma, *bn_beta, *bn_mean, *bn_rstd;
     int bn_pooled;        // 0: the layer has no pool, bn_pre has this output's shape
+    // optional stream signal (see StreamSignal): the first block stores `signal_value` here as
+    // it starts, which tells a waiting queue that everything before this kernel has completed
+    unsigned* signal;
+    unsigned signal_value;
 };
+
+__device__ __forceinline__ void raise_stream_signal(const IgemmArgs& p) {
+    if (p.signal && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        __hip_atomic_store(p.signal, p.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int kOutOfRange = (int)0x80000000;   // voffset beyond any tensor: hardware returns zeros
@@ -305,6 +314,7 @@ __device__ __forceinline__ void bn_plain_bwd_tile_sums(const f32x4 (&acc)[TN][TM
 // bounds small tiles: bytes per flop fall with tile size).
 template <int BM, int BN, int WAVES_M, int EPI, bool SPLIT, int NS, bool PM, int NW>
 __global__ __launch_bounds__(NW * 64) void conv3x3_igemm_kernel(IgemmArgs p) {
+    raise_stream_signal(p);
     constexpr int WAVES_N = NW / WAVES_M;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -803,6 +813,7 @@ void launch_layout(const IgemmArgs& a, int epi, int splits, bool pm, hipStream_t
 // though tap 0 issues extra loads.
 template <int BM, int BN, int NW, int EPI>
 __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(IgemmArgs p) {
+    raise_stream_signal(p);
     constexpr int WAVES_M = 2, WAVES_N = NW / 2;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -1098,7 +1109,8 @@ int conv3x3_igemm_stats_rows(ConvShape s) {
 void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const float* bias,
                    const bf16_raw* mask, float* workspace, size_t workspace_elems, ConvShape s,
                    ConvEpilogue epi, hipStream_t stream, const int* force_plan, float* stats,
-                   SplitSlabs* defer, const BnPoolReduce* bn_pool, BnPartials* bn_done) {
+                   SplitSlabs* defer, const BnPoolReduce* bn_pool, BnPartials* bn_done,
+                   const StreamSignal* signal) {
     check_shape(s, "conv3x3_igemm");
     if (bn_done) *bn_done = BnPartials{};
     if (bn_pool && (epi != EPI_NONE || stats || !bn_done || !bn_pool->pre || !bn_pool->partials))
@@ -1117,6 +1129,8 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
     a.stats = stats;
     a.bn_pre = nullptr; a.bn_gamma = a.bn_beta = a.bn_mean = a.bn_rstd = nullptr;
     a.bn_pooled = 1;
+    a.signal = signal ? signal->flag : nullptr;
+    a.signal_value = signal ? signal->value : 0u;
     if (stats && (epi != EPI_BIAS || force_plan))
         throw std::invalid_argument("conv3x3_igemm: statistics come with the default plan and "
                                     "the bias-only epilogue");
