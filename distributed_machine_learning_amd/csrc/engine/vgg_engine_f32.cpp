@@ -13,6 +13,7 @@
 //   loss    : classifier rows + batch reductions (logits, loss, dlogits, dx, dW, db)
 //   backward: [pool bwd] -> [BatchNorm+ReLU bwd] -> bias grad -> wgrad (+ slab sum) -> dgrad
 //   update  : reducer wait / manual sync -> fused SGD -> backward-data weight repacks
+#include <cstring>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -130,13 +131,15 @@ void VggEngineF32::set_wgrad_overlap(bool on, hipStream_t compute_stream) {
         if (reducer_ && reducer_->comm_stream()) avoid.push_back(reducer_->comm_stream());
         side_ = create_concurrent_stream(avoid);
         grad_ready_.resize(lay_.convs.size());
+        // (events between two queues of one GPU: no system-scope fence of their own, the kernels
+        // release their writes to the device as they end; DML_EVENT_SCOPE=system restores it)
+        unsigned flags = hipEventDisableTiming | hipEventDisableSystemFence;
+        if (const char* e = getenv("DML_EVENT_SCOPE"))
+            if (!strcmp(e, "system")) flags = hipEventDisableTiming;
         for (hipEvent_t& e : grad_ready_)
-            check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-        check_hip(hipEventCreateWithFlags(&side_done_, hipEventDisableTiming), "hipEventCreate");
-        check_hip(hipEventCreateWithFlags(&updated_, hipEventDisableTiming), "hipEventCreate");
-        check_hip(hipEventCreateWithFlags(&repack_done_, hipEventDisableTiming), "hipEventCreate");
-        check_hip(hipEventCreateWithFlags(&fwd_begin_, hipEventDisableTiming), "hipEventCreate");
-        check_hip(hipEventCreateWithFlags(&cleared_, hipEventDisableTiming), "hipEventCreate");
+            check_hip(hipEventCreateWithFlags(&e, flags), "hipEventCreate");
+        for (hipEvent_t* e : {&side_done_, &updated_, &repack_done_, &fwd_begin_, &cleared_})
+            check_hip(hipEventCreateWithFlags(e, flags), "hipEventCreate");
     }
     overlap_ = on;
 }
