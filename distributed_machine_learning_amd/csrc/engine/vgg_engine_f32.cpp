@@ -122,6 +122,7 @@ VggEngineF32::~VggEngineF32() {
     if (fwd_begin_) (void)hipEventDestroy(fwd_begin_);
     if (cleared_) (void)hipEventDestroy(cleared_);
     if (side_) (void)hipStreamDestroy(side_);
+    if (hand_off_flags_) (void)hipFree(hand_off_flags_);
 }
 
 void VggEngineF32::set_wgrad_overlap(bool on, hipStream_t compute_stream) {
@@ -140,6 +141,17 @@ void VggEngineF32::set_wgrad_overlap(bool on, hipStream_t compute_stream) {
             check_hip(hipEventCreateWithFlags(&e, flags), "hipEventCreate");
         for (hipEvent_t* e : {&side_done_, &updated_, &repack_done_, &fwd_begin_, &cleared_})
             check_hip(hipEventCreateWithFlags(e, flags), "hipEventCreate");
+        int can_wait_value = 0, device = 0;
+        check_hip(hipGetDevice(&device), "hipGetDevice");
+        (void)hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device);
+        const char* mode = getenv("DML_HANDOFF");
+        value_hand_off_ = can_wait_value && !(mode && !strcmp(mode, "event"));
+        if (value_hand_off_) {
+            const size_t bytes = lay_.convs.size() * sizeof(unsigned);
+            check_hip(hipMalloc((void**)&hand_off_flags_, bytes), "hipMalloc(hand-off flags)");
+            check_hip(hipMemset(hand_off_flags_, 0, bytes), "hipMemset(hand-off flags)");
+            check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(hand-off flags)");
+        }
     }
     overlap_ = on;
 }
@@ -320,6 +332,8 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
     join_clear(stream);
     sums_.n = 0;
     float* tb = arena_ + tb_off_;
+    const bool by_value = overlap_ && value_hand_off_;
+    if (by_value) ++backward_seq_;
 
     const ParamLayout::Conv& last = lay_.convs[nconv - 1];
     const float* fc_in = arena_ + (last.pool_after ? buf_[nconv - 1].pool_off : buf_[nconv - 1].out_off);
@@ -358,18 +372,25 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
         // nothing else left and the side stream still has the second layer's to finish)
         hipStream_t wstream = stream;
         if (overlap_ && i > 0) {
-            check_hip(hipEventRecord(grad_ready_[i], stream), "hipEventRecord(grad ready)");
+            if (!by_value)
+                check_hip(hipEventRecord(grad_ready_[i], stream), "hipEventRecord(grad ready)");
             wstream = side_;
         }
+        // by value: the backward-data kernel, next in the main queue, raises the layer's flag
+        const StreamSignal raise = {hand_off_flags_ ? hand_off_flags_ + i : nullptr, backward_seq_};
         if (i > 0) {
             // input gradient; the producer's ReLU is folded in when nothing sits in between
             const bool fold = direct(i - 1);
             conv3x3_igemm_f32(g, arena_ + b.wd_off, arriving(i - 1), nullptr,
                               fold ? arena_ + buf_[i - 1].out_off : nullptr,
                               {batch, c.hw, c.cout, c.cin}, fold ? EPI_MASK : EPI_NONE, stream,
-                              0, -1, -1, bwd_cleared_[i] != 0);
+                              0, -1, -1, bwd_cleared_[i] != 0, by_value ? &raise : nullptr);
         }
-        if (overlap_ && i > 0)
+        if (by_value && i > 0)
+            check_hip(hipStreamWaitValue32(side_, hand_off_flags_ + i, backward_seq_,
+                                           hipStreamWaitValueGte, 0xffffffffu),
+                      "hipStreamWaitValue32(grad ready)");
+        else if (overlap_ && i > 0)
             check_hip(hipStreamWaitEvent(side_, grad_ready_[i], 0), "hipStreamWaitEvent(grad ready)");
         if (i == 0) {
             // Conv bias gradient under BatchNorm: exactly zero in exact arithmetic (the

@@ -296,6 +296,10 @@ class VggEngineF32 {
     bool overlap_ = false;
     hipStream_t side_ = nullptr;
     std::vector<hipEvent_t> grad_ready_;    // per layer: dL/d(conv output) complete on the main stream
+    // the same hand-offs through flag words and wait-value packets (see StreamSignal)
+    unsigned* hand_off_flags_ = nullptr;
+    unsigned backward_seq_ = 0;
+    bool value_hand_off_ = false;
     hipEvent_t side_done_ = nullptr, updated_ = nullptr, repack_done_ = nullptr;
     bool repack_pending_ = false;           // weight layouts of the last update still on the side stream
     void join_repack(hipStream_t stream);

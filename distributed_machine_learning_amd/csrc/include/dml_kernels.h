@@ -356,7 +356,8 @@ void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bi
                        int force_tile = 0 /* tuning: 128 or 64 */,
                        int force_pm = -1 /* tuning: position-major tiles off / on */,
                        int force_split = -1 /* tuning: two-way tap split off / on (-1: by grid size) */,
-                       bool pre_zeroed = false /* y is already zero: skip the tap split's memset */);
+                       bool pre_zeroed = false /* y is already zero: skip the tap split's memset */,
+                       const StreamSignal* signal = nullptr /* raised as the kernel starts */);
 // 2 when the default plan divides the taps of a position between two blocks that meet in y through
 // atomics - y must then be zero before the launch (the launcher clears it unless pre_zeroed)
 int conv3x3_igemm_f32_tap_splits(ConvShape s, ConvEpilogue epi);

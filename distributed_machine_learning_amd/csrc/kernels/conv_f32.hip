@@ -61,6 +61,10 @@ struct IgemmParams {
     // (0 + a = a exactly, a + b = b + a), so the kernel stays bit-reproducible; bias and ReLU mask
     // distribute over the two parts, a ReLU would not (EPI_BIAS_RELU is never split).
     int tap_splits;
+    // optional hand-off to another queue (see StreamSignal): the first block stores the value
+    // as it starts
+    unsigned* signal;
+    unsigned signal_value;
 };
 
 // (waves_per_eu: without the cap hipcc aims for 7 waves per SIMD on the 64 x 64 variant and
@@ -68,6 +72,8 @@ struct IgemmParams {
 template <int MT, int NT, bool PM, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
 void conv3x3_igemm_f32_kernel(IgemmParams p) {
+    if (p.signal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(p.signal, p.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     constexpr int BM = 64 * MT, BN = 64 * NT;
     constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;     // float4 loads per thread and chunk
     __shared__ __attribute__((aligned(16))) float As[2][BM * kBK];
@@ -611,7 +617,8 @@ int conv3x3_igemm_f32_tap_splits(ConvShape s, ConvEpilogue epi) {
 
 void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bias,
                        const float* mask, ConvShape s, ConvEpilogue epi, hipStream_t stream,
-                       int force_tile, int force_pm, int force_split, bool pre_zeroed) {
+                       int force_tile, int force_pm, int force_split, bool pre_zeroed,
+                       const StreamSignal* signal) {
     check_shape(s, "conv3x3_igemm_f32");
     if (!x || !w || !y) throw std::invalid_argument("conv3x3_igemm_f32: null tensor");
     if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias)
@@ -622,6 +629,8 @@ void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bi
     p.x = x; p.w = w; p.y = y; p.bias = bias; p.mask = mask;
     p.M = s.batch * s.hw * s.hw; p.N = s.cout; p.cin = s.cin; p.hw = s.hw;
     p.log_hw = log2_exact(s.hw); p.batch = s.batch;
+    p.signal = signal ? signal->flag : nullptr;
+    p.signal_value = signal ? signal->value : 0u;
     const IgemmPlan pl = plan_igemm(s, epi, force_tile, force_pm, force_split);
     p.tap_splits = pl.tap_splits;
     if (pl.tap_splits == 2 && !pre_zeroed)
