@@ -308,40 +308,51 @@ def run_rank(ns) -> None:
     loss = last if last is not None else loss
     final_loss = float(loss.item()) if loss is not None else float("nan")
 
-    # ---- everything below is outside the measured region
-    windows = [timed(ns.steps)[0] for _ in range(max(ns.windows, 0))]
+    # ---- everything below is outside the measured region.  The extras (further windows, host
+    # probe, self checks, communication split) must never cost the run its record: a failure in
+    # one of them is reported in the record's `extras_error` and in the exit code instead.
+    extras_error = None
+    windows = []
+    host_elapsed = float("nan")
     probe = 20                                  # host cost of enqueueing steps into an empty queue
-    t1 = time.perf_counter()
-    for i in range(probe):
-        backend.train_step(*batches[i % len(batches)])
-    host_elapsed = time.perf_counter() - t1
-    barrier()
-
-    # ---- cross-rank self checks
-    per_rank_ms = [elapsed / ns.steps * 1e3]
-    nranks_seen = 1
+    per_rank_ms = [round(elapsed / ns.steps * 1e3, 4)]
+    nranks_seen = comm.peer_count if comm is not None else 1
     in_sync = None
-    if comm is not None:
-        nranks_seen = comm.peer_count
-        times = comm.all_gather_scalars(elapsed, torch.float32)
-        per_rank_ms = [round(float(t) / ns.steps * 1e3, 4) for t in times]
-        elapsed = float(times.max())                        # MAX over ranks
-        if windows:
-            w = torch.zeros(world, len(windows), device=device)
-            w[rank] = torch.tensor(windows, device=device)
-            comm.all_reduce(w)
-            comm.guard_sync(ns.comm_timeout)
-            windows = [float(v) for v in w.max(dim=0).values.cpu()]
-        # bit pattern checksum of the master weights: equal on every rank, or training diverged
-        flat = backend.parameters_flat()
-        checksum = int(flat.view(torch.int32).to(torch.int64).sum().item())
-        sums = comm.all_gather_scalars(checksum, torch.int64)
-        in_sync = bool((sums == sums[0]).all())
-
     overlap = None
-    if comm is not None and (world > 1 or ns.report_overlap):
-        from distributed_machine_learning_amd.utils.overlap import measure_comm_split
-        overlap = measure_comm_split(backend, comm, batches, n=max(10, min(ns.steps, 50)))
+    try:
+        windows = [timed(ns.steps)[0] for _ in range(max(ns.windows, 0))]
+        t1 = time.perf_counter()
+        for i in range(probe):
+            backend.train_step(*batches[i % len(batches)])
+        host_elapsed = time.perf_counter() - t1
+        barrier()
+
+        # ---- cross-rank self checks
+        if comm is not None:
+            times = comm.all_gather_scalars(elapsed, torch.float32)
+            per_rank_ms = [round(float(t) / ns.steps * 1e3, 4) for t in times]
+            elapsed = float(times.max())                        # MAX over ranks
+            if windows:
+                w = torch.zeros(world, len(windows), device=device)
+                w[rank] = torch.tensor(windows, device=device)
+                comm.all_reduce(w)
+                comm.guard_sync(ns.comm_timeout)
+                windows = [float(v) for v in w.max(dim=0).values.cpu()]
+            # bit pattern checksum of the master weights: equal on every rank, or training diverged
+            flat = backend.parameters_flat()
+            checksum = int(flat.view(torch.int32).to(torch.int64).sum().item())
+            sums = comm.all_gather_scalars(checksum, torch.int64)
+            in_sync = bool((sums == sums[0]).all())
+
+        if comm is not None and (world > 1 or ns.report_overlap):
+            from distributed_machine_learning_amd.utils.overlap import measure_comm_split
+            overlap = measure_comm_split(backend, comm, batches, n=max(10, min(ns.steps, 50)))
+    except Exception as exc:                    # noqa: BLE001 - reported, then the run fails
+        extras_error = f"{type(exc).__name__}: {exc}"
+        print(f"[bench] rank {rank}: after the measured region: {extras_error}", file=sys.stderr)
+        if comm is not None and len(per_rank_ms) == 1 and world > 1:
+            # the MAX over ranks could not be taken: say so instead of passing off one rank's time
+            extras_error += " (ms_per_step is rank 0's own time, not the maximum over ranks)"
 
     if rank == 0:
         ms = elapsed / ns.steps * 1e3
@@ -357,6 +368,7 @@ def run_rank(ns) -> None:
             "dtype": ns.dtype, "data": "synthetic",
             "rccl_nranks": nranks_seen, "transport": ns.transport if comm is not None else "none",
             "per_rank_ms_per_step": per_rank_ms, "params_in_sync": in_sync,
+            "extras_error": extras_error,
             "windows": ({"n": len(win_ms), "steps_each": ns.steps,
                          "min_ms_per_step": round(win_ms[0], 4),
                          "median_ms_per_step": round(win_ms[len(win_ms) // 2], 4),
@@ -377,6 +389,10 @@ def run_rank(ns) -> None:
                        "baseline": f"reference {ns.mode}: {REFERENCE_IMAGES_PER_SEC[ns.mode]} "
                                    "images/s on its CPU cluster (group25.pdf)"}}
         print(json.dumps(record), file=json_out, flush=True)
+    if extras_error is not None:
+        # (a failed collective may have left the communicator unusable: no orderly teardown)
+        sys.stderr.flush()
+        os._exit(3)
     backend.close()
     if comm is not None:
         comm.destroy()

@@ -73,7 +73,7 @@ template <int MT, int NT, bool PM, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
 void conv3x3_igemm_f32_kernel(IgemmParams p) {
     if (p.signal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-        __hip_atomic_store(p.signal, p.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.signal, p.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     constexpr int BM = 64 * MT, BN = 64 * NT;
     constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;     // float4 loads per thread and chunk
     __shared__ __attribute__((aligned(16))) float As[2][BM * kBK];

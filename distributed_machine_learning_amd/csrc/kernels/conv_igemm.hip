@@ -75,7 +75,7 @@ struct IgemmArgs {
 
 __device__ __forceinline__ void raise_stream_signal(const IgemmArgs& p) {
     if (p.signal && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-        __hip_atomic_store(p.signal, p.signal_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.signal, p.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
