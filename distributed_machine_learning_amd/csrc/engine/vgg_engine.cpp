@@ -925,6 +925,7 @@ void bind_engine(py::module_& m) {
         .def_property_readonly("update_overlap", &VggEngine::update_overlap)
         .def("join_update", [](VggEngine& e, uintptr_t s) { e.join_update((hipStream_t)s); })
         .def_property_readonly("wgrad_overlap", &VggEngine::wgrad_overlap)
+        .def_property_readonly("hand_off_mode", [](const VggEngine& e) { return std::string(e.hand_off_mode()); })
         .def_property_readonly("wgrad_stream", [](VggEngine& e) { return (uintptr_t)e.wgrad_stream(); })
         .def("set_reducer", [](VggEngine& e, BucketReducer* r,
                                std::vector<std::pair<int, int>> buckets) {

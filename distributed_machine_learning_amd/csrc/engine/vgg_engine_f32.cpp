@@ -522,6 +522,7 @@ void bind_engine_f32(py::module_& m) {
             e.set_wgrad_overlap(on, (hipStream_t)compute_stream);
         }, py::arg("on"), py::arg("compute_stream") = 0)
         .def_property_readonly("wgrad_overlap", &VggEngineF32::wgrad_overlap)
+        .def_property_readonly("hand_off_mode", [](const VggEngineF32& e) { return std::string(e.hand_off_mode()); })
         .def_property_readonly("wgrad_stream", [](VggEngineF32& e) { return (uintptr_t)e.wgrad_stream(); })
         .def("refresh_weights", [](VggEngineF32& e, uintptr_t s) { e.refresh_weights((hipStream_t)s); })
         .def("forward", [](VggEngineF32& e, uintptr_t x, int batch, bool training, uintptr_t s) {

@@ -86,6 +86,8 @@ class VggEngine {
     void set_fused_optimizer(bool on, float lr = 0.f, float momentum = 0.f,
                              float weight_decay = 0.f, float grad_scale = 1.f);
     bool wgrad_overlap() const { return wgrad_overlap_; }
+    // "value": flag word + wait-value packet, "event": event pair (see StreamSignal)
+    const char* hand_off_mode() const { return value_hand_off_ ? "value" : "event"; }
     hipStream_t wgrad_stream() const { return wgrad_stream_; }
     // Overlap the parameter update of the deep layers with the first layers of the NEXT forward
     // (side-stream mode only).  optimizer_step() then updates and repacks the conv layers below
@@ -264,6 +266,7 @@ class VggEngineF32 {
     // main stream joins it at the end of backward.  Same kernels on the same values.
     void set_wgrad_overlap(bool on, hipStream_t compute_stream = nullptr);
     bool wgrad_overlap() const { return overlap_; }
+    const char* hand_off_mode() const { return value_hand_off_ ? "value" : "event"; }
     hipStream_t wgrad_stream() const { return side_; }
     ~VggEngineF32();
 

@@ -18,8 +18,8 @@ def _mk(batch_norm, batch=32, sync="none", comm=None, arch="VGG11", **kw):
     from distributed_machine_learning_amd.models import VGG
     torch.manual_seed(1234)
     ref = VGG(arch, batch_norm).to(DEV)
-    cfg = TrainConfig(batch_size=batch, batch_norm=batch_norm, sync=sync, dtype="bf16",
-                      backend="native", lr=0.01, arch=arch, **kw)
+    cfg = TrainConfig(batch_size=batch, batch_norm=batch_norm, sync=sync,
+                      dtype=kw.pop("dtype", "bf16"), backend="native", lr=0.01, arch=arch, **kw)
     nb = NativeBackend(cfg, DEV, comm, init_state=ref.state_dict())
     return nb, ref
 
@@ -381,6 +381,35 @@ def test_wgrad_side_stream_matches_single_stream(batch_norm, mode):
     finally:
         if comm is not None:
             comm.destroy()
+
+
+@pytest.mark.parametrize("batch_norm", [False, True])
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_flag_word_hand_offs_match_event_hand_offs(batch_norm, dtype, monkeypatch):
+    """The side stream learns that a layer's gradient is complete either from an event pair or
+    from a flag word raised by the following backward-data kernel (hipStreamWaitValue32 on the
+    side queue).  Both must give the bits of the single-stream schedule."""
+    kw = {"dtype": dtype} if dtype == "fp32" else {}
+    monkeypatch.setenv("DML_HANDOFF", "event")
+    by_event, _ = _mk(batch_norm, batch=64, wgrad_overlap=True, **kw)
+    monkeypatch.delenv("DML_HANDOFF")
+    by_value, _ = _mk(batch_norm, batch=64, wgrad_overlap=True, **kw)
+    base, _ = _mk(batch_norm, batch=64, wgrad_overlap=False, **kw)
+    assert by_event.engine.hand_off_mode == "event"
+    assert by_value.engine.hand_off_mode == "value"     # MI355X / ROCm 7 supports wait-value
+    for step in range(6):
+        _, x4, t = _batch(64, seed=step)
+        xin = x4 if dtype == "bf16" else x4.float()
+        la = base.train_step(xin, t).clone()
+        lb = by_event.train_step(xin, t).clone()
+        lc = by_value.train_step(xin, t).clone()
+        assert torch.equal(la, lb) and torch.equal(la, lc), (step, float(la), float(lb), float(lc))
+    torch.cuda.synchronize()
+    for other in (by_event, by_value):
+        assert torch.equal(other.params, base.params)
+        assert torch.equal(other.momentum, base.momentum)
+        other.close()
+    base.close()
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
