@@ -304,7 +304,10 @@ def run_rank(ns) -> None:
     loss = None
     for i in range(ns.warmup):
         loss = backend.train_step(*batches[i % len(batches)])
+    if comm is not None:
+        comm.reset_volume()                     # (host-side counters of what gets issued)
     elapsed, last = timed(ns.steps)             # THE measured region: exactly --steps steps
+    volume = comm.volume() if comm is not None else None
     loss = last if last is not None else loss
     final_loss = float(loss.item()) if loss is not None else float("nan")
 
@@ -369,6 +372,13 @@ def run_rank(ns) -> None:
             "rccl_nranks": nranks_seen, "transport": ns.transport if comm is not None else "none",
             "per_rank_ms_per_step": per_rank_ms, "params_in_sync": in_sync,
             "extras_error": extras_error,
+            # bytes rank 0 put on / took off its links per step (ring all-reduce, direct
+            # gather / scatter), from the collectives issued inside the measured region
+            # (its two barriers' 4-byte tokens included)
+            "comm_bytes_per_step": ({"tx": volume["tx_bytes"] // ns.steps,
+                                     "rx": volume["rx_bytes"] // ns.steps,
+                                     "calls": {k: v for k, v in volume["calls"].items() if v}}
+                                    if volume is not None else None),
             "windows": ({"n": len(win_ms), "steps_each": ns.steps,
                          "min_ms_per_step": round(win_ms[0], 4),
                          "median_ms_per_step": round(win_ms[len(win_ms) // 2], 4),

@@ -87,6 +87,11 @@ def build_parser(defaults: TrainConfig, distributed_flags: bool = True) -> argpa
     p.add_argument("--report-overlap", action="store_true", default=defaults.report_overlap,
                    help="after training: time the step with and without its collectives and "
                         "the collectives alone; print the exposed time and overlap fraction")
+    p.add_argument("--report-comm-volume", action="store_true",
+                   default=defaults.report_comm_volume,
+                   help="after the training iterations: bytes this rank put on / took off its "
+                        "links and the collectives it issued (the reference's report samples "
+                        "this per node, group25.pdf p4, p6, p8)")
     p.add_argument("--save", dest="checkpoint_out", type=str, default=None)
     p.add_argument("--load", dest="checkpoint_in", type=str, default=None)
     p.add_argument("--threads", type=int, default=defaults.threads)

@@ -86,6 +86,7 @@ class TrainConfig:
     json: bool = False
     profile_ranges: bool = False
     report_overlap: bool = False           # after the run: comm/compute split of a step
+    report_comm_volume: bool = False       # after the epoch: bytes this rank sent / received
     checkpoint_out: Optional[str] = None
     checkpoint_in: Optional[str] = None
 

@@ -7,6 +7,8 @@
 // started as soon as backward has produced its last gradient, overlapping the rest of
 // backward.  Here a bucket is a slice of the flat gradient buffer, the all-reduce runs in
 // place on a dedicated HIP stream, and ordering is expressed with HIP events only.
+#include <cstring>
+#include <cstdlib>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -63,9 +65,14 @@ BucketReducer::BucketReducer(Comm* comm, float* flat_grads, std::vector<Slice> s
     ready_.resize(slices_.size());
     done_.resize(slices_.size());
     launched_.assign(slices_.size(), 0);
+    unsigned ready_flags = kEventFlags, done_flags = kEventFlags;
+    if (const char* e = getenv("DML_REDUCER_EVENT_SCOPE")) {        // measurement knob
+        if (strstr(e, "ready-nofence")) ready_flags |= hipEventDisableSystemFence;
+        if (strstr(e, "done-nofence")) done_flags |= hipEventDisableSystemFence;
+    }
     for (size_t i = 0; i < slices_.size(); ++i) {
-        check_hip(hipEventCreateWithFlags(&ready_[i], kEventFlags), "hipEventCreate");
-        check_hip(hipEventCreateWithFlags(&done_[i], kEventFlags), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&ready_[i], ready_flags), "hipEventCreate");
+        check_hip(hipEventCreateWithFlags(&done_[i], done_flags), "hipEventCreate");
     }
 }
 
@@ -218,7 +225,29 @@ void bind_comm(py::module_& m) {
 
     m.def("rccl_unique_id", []() { return py::bytes(RcclComm::unique_id()); });
 
+    m.def("link_bytes", [](int kind, uint64_t payload, int world, bool is_root) {
+        uint64_t tx = 0, rx = 0;
+        link_bytes((CollKind)kind, payload, world, is_root, &tx, &rx);
+        return py::make_tuple(tx, rx);
+    }, py::arg("kind"), py::arg("payload_bytes"), py::arg("world"), py::arg("is_root"));
+
     py::class_<Comm>(m, "Comm")
+        .def("volume", [](const Comm& c) {
+            const CommVolume& v = c.volume();
+            py::dict d;
+            d["tx_bytes"] = v.tx_bytes;
+            d["rx_bytes"] = v.rx_bytes;
+            const char* names[4] = {"all_reduce", "broadcast", "gather", "scatter"};
+            py::dict calls, payload;
+            for (int k = 0; k < 4; ++k) {
+                calls[names[k]] = v.calls[k];
+                payload[names[k]] = v.payload_bytes[k];
+            }
+            d["calls"] = calls;
+            d["payload_bytes"] = payload;
+            return d;
+        })
+        .def("reset_volume", &Comm::reset_volume)
         .def_property_readonly("rank", &Comm::rank)
         .def_property_readonly("world_size", &Comm::world_size)
         .def_property_readonly("transport", [](Comm& c) { return std::string(c.transport()); })

@@ -383,6 +383,7 @@ int LoopbackComm::peer_count() { return impl_->hdr ? impl_->hdr->world : -1; }
 
 void LoopbackComm::all_reduce(void* buf, size_t count, DType dt, bool average, hipStream_t stream) {
     if (count == 0) return;
+    account(COLL_ALL_REDUCE, count, dt, rank_);
     Impl& s = *impl_;
     s.check_usable();
     const size_t esz = dtype_bytes(dt), per = kStage / esz;
@@ -401,6 +402,7 @@ void LoopbackComm::all_reduce(void* buf, size_t count, DType dt, bool average, h
 void LoopbackComm::broadcast(const void* send, void* recv, size_t count, DType dt, int root,
                              hipStream_t stream) {
     if (count == 0) return;
+    account(COLL_BROADCAST, count, dt, root);
     Impl& s = *impl_;
     s.check_usable();
     const size_t esz = dtype_bytes(dt), per = kStage / esz;
@@ -423,6 +425,7 @@ void LoopbackComm::broadcast(const void* send, void* recv, size_t count, DType d
 void LoopbackComm::gather(const void* send, const std::vector<void*>& recv, size_t count, DType dt,
                           int root, hipStream_t stream) {
     if (count == 0) return;
+    account(COLL_GATHER, count, dt, root);
     if (rank_ == root && (int)recv.size() != world_)
         throw std::invalid_argument("LoopbackComm::gather: root needs world_size receive slabs");
     Impl& s = *impl_;
@@ -452,6 +455,7 @@ void LoopbackComm::gather(const void* send, const std::vector<void*>& recv, size
 void LoopbackComm::scatter(void* out, const std::vector<const void*>& chunks, size_t count,
                            DType dt, int root, hipStream_t stream) {
     if (count == 0) return;
+    account(COLL_SCATTER, count, dt, root);
     if (rank_ == root && (int)chunks.size() != world_)
         throw std::invalid_argument("LoopbackComm::scatter: root needs world_size chunks");
     Impl& s = *impl_;

@@ -51,6 +51,28 @@ size_t dtype_bytes(DType dt) {
     throw std::invalid_argument("unknown dtype code");
 }
 
+void link_bytes(CollKind kind, uint64_t payload_bytes, int world, bool is_root, uint64_t* tx,
+                uint64_t* rx) {
+    *tx = *rx = 0;
+    if (world <= 1) return;                 // a group of one moves nothing
+    const uint64_t w = (uint64_t)world;
+    switch (kind) {
+        case COLL_ALL_REDUCE:               // ring: reduce-scatter + all-gather
+            *tx = *rx = 2 * (w - 1) * payload_bytes / w;
+            return;
+        case COLL_BROADCAST:                // the payload leaves the root once and arrives once
+            if (is_root) *tx = payload_bytes; else *rx = payload_bytes;
+            return;
+        case COLL_GATHER:                   // every other rank sends its payload to the root
+            if (is_root) *rx = (w - 1) * payload_bytes; else *tx = payload_bytes;
+            return;
+        case COLL_SCATTER:
+            if (is_root) *tx = (w - 1) * payload_bytes; else *rx = payload_bytes;
+            return;
+    }
+    throw std::invalid_argument("link_bytes: unknown collective");
+}
+
 std::string RcclComm::unique_id() {
     ncclUniqueId id;
     check_nccl(ncclGetUniqueId(&id), "ncclGetUniqueId");
@@ -113,6 +135,7 @@ void RcclComm::group_end() {
 
 void RcclComm::all_reduce(void* buf, size_t count, DType dt, bool average, hipStream_t stream) {
     if (count == 0) return;
+    account(COLL_ALL_REDUCE, count, dt, rank_);
     check_nccl(ncclAllReduce(buf, buf, count, nccl_type(dt), average ? ncclAvg : ncclSum,
                              (ncclComm_t)comm_, stream),
                "ncclAllReduce");
@@ -121,6 +144,7 @@ void RcclComm::all_reduce(void* buf, size_t count, DType dt, bool average, hipSt
 void RcclComm::broadcast(const void* send, void* recv, size_t count, DType dt, int root,
                          hipStream_t stream) {
     if (count == 0) return;
+    account(COLL_BROADCAST, count, dt, root);
     check_nccl(ncclBroadcast(send, recv, count, nccl_type(dt), root, (ncclComm_t)comm_, stream),
                "ncclBroadcast");
 }
@@ -128,6 +152,7 @@ void RcclComm::broadcast(const void* send, void* recv, size_t count, DType dt, i
 void RcclComm::gather(const void* send, const std::vector<void*>& recv, size_t count, DType dt,
                       int root, hipStream_t stream) {
     if (count == 0) return;
+    account(COLL_GATHER, count, dt, root);
     const ncclDataType_t t = nccl_type(dt);
     if (rank_ == root) {
         if ((int)recv.size() != world_)
@@ -147,6 +172,7 @@ void RcclComm::gather(const void* send, const std::vector<void*>& recv, size_t c
 void RcclComm::scatter(void* out, const std::vector<const void*>& chunks, size_t count, DType dt,
                        int root, hipStream_t stream) {
     if (count == 0) return;
+    account(COLL_SCATTER, count, dt, root);
     const ncclDataType_t t = nccl_type(dt);
     if (rank_ == root) {
         if ((int)chunks.size() != world_)

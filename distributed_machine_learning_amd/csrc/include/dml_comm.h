@@ -61,6 +61,21 @@ class TcpStore {
 enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_I64 = 2, DT_U8 = 3 };
 size_t dtype_bytes(DType dt);
 
+// Bytes a rank puts on (tx) and takes off (rx) its links, by the algorithms the transports run:
+// all-reduce as a ring (2 (W-1)/W of the payload each way), gather / scatter as direct transfers
+// to / from the root ((W-1) payloads at the root, one at every other rank), broadcast as a chain
+// from the root.  The reference's report samples exactly this per node (group25.pdf p4, p6, p8:
+// node 0 moves ~4.4 GB each way in 40 iterations of gather/scatter against ~1.5 GB elsewhere,
+// ~2.2 GB per node with all-reduce); the counters below reproduce it from what was issued.
+enum CollKind : int { COLL_ALL_REDUCE = 0, COLL_BROADCAST = 1, COLL_GATHER = 2, COLL_SCATTER = 3 };
+void link_bytes(CollKind kind, uint64_t payload_bytes, int world, bool is_root, uint64_t* tx,
+                uint64_t* rx);
+struct CommVolume {
+    uint64_t tx_bytes = 0, rx_bytes = 0;
+    uint64_t calls[4] = {0, 0, 0, 0};       // indexed by CollKind
+    uint64_t payload_bytes[4] = {0, 0, 0, 0};
+};
+
 // The collective surface of the three sync modes.  Every call enqueues on the caller's HIP
 // stream and returns; calls on one communicator must be issued in the same order on every rank.
 //
@@ -99,10 +114,24 @@ class Comm {
     // into a clean non-zero exit instead of a hang.
     virtual void wait_stream(hipStream_t stream, double timeout_s) = 0;
     virtual void destroy() = 0;
+    // what this rank has issued since construction / the last reset (host-side bookkeeping)
+    const CommVolume& volume() const { return volume_; }
+    void reset_volume() { volume_ = CommVolume{}; }
 
   protected:
     Comm(int rank, int world) : rank_(rank), world_(world) {}
+    // every transport calls this once per collective it issues
+    void account(CollKind kind, size_t count, DType dt, int root) {
+        uint64_t tx = 0, rx = 0;
+        const uint64_t bytes = (uint64_t)count * dtype_bytes(dt);
+        link_bytes(kind, bytes, world_, rank_ == root, &tx, &rx);
+        volume_.tx_bytes += tx;
+        volume_.rx_bytes += rx;
+        volume_.calls[kind] += 1;
+        volume_.payload_bytes[kind] += bytes;
+    }
     int rank_, world_;
+    CommVolume volume_;
 };
 
 // ------------------------------------------------------------------------ RcclComm

@@ -103,9 +103,14 @@ class Trainer:
         if cfg.announce_epoch:
             print(f"Epoch {epoch} triggered")
         self.backend.train_mode(True)
+        count_volume = cfg.report_comm_volume and hasattr(self.comm, "reset_volume")
+        if count_volume:
+            self.comm.reset_volume()
+        done = 0
         for batch_idx, (data, target) in enumerate(loader):
             if batch_idx == cfg.iters:
                 break
+            done += 1
             timer.start()
             with prof.range("train_step", cfg.profile_ranges):
                 loss = self.backend.train_step(data, target)
@@ -125,6 +130,12 @@ class Trainer:
             global_batch = cfg.batch_size * self.world
             print(f"Throughput: {global_batch / per_iter:.1f} images/sec "
                   f"({cfg.batch_size} img/rank x {self.world} ranks, {per_iter*1e3:.3f} ms/iter)")
+        if count_volume:
+            self.last_volume = vol = self.comm.volume()
+            calls = ", ".join(f"{n} {k}" for k, n in vol["calls"].items() if n)
+            print(f"[rank {self.rank}] communication volume over {done} iterations: "
+                  f"TX {vol['tx_bytes'] / 1e9:.3f} GB, RX {vol['rx_bytes'] / 1e9:.3f} GB "
+                  f"({calls or 'no collectives'})")
         self.last_timer = timer
         return timer
 
@@ -191,6 +202,8 @@ class Trainer:
             from ..models.checkpoint import save_checkpoint
             save_checkpoint(cfg.checkpoint_out, self.backend.state_dict(),
                             ddp_prefix=cfg.sync == "ddp")
+        if getattr(self, "last_volume", None) is not None:
+            result["comm_volume"] = self.last_volume
         if cfg.report_overlap:
             split = self.comm_split(train_loader)
             if split is not None:

@@ -230,6 +230,15 @@ class RcclCommunicator(Communicator):
         self.guard_sync(self.timeout_s)
         return v.cpu()
 
+    def volume(self) -> dict:
+        """Bytes this rank has put on / taken off its links since the last ``reset_volume`` and
+        the number of collectives of each kind, as issued (what the reference's report samples
+        per node with an external tool, group25.pdf p4, p6, p8)."""
+        return dict(self._comm.volume())
+
+    def reset_volume(self) -> None:
+        self._comm.reset_volume()
+
     def group_start(self):
         self._comm.group_start()
 

@@ -485,6 +485,22 @@ def test_cli_on_gpu_prints_reference_lines(capsys):
     assert res["avg_s_per_iter"] > 0
 
 
+def test_cli_reports_communication_volume(capsys):
+    """--report-comm-volume: the collectives the run issued and the bytes they moved.  A group
+    of one issues the reference's 18 all_reduce calls per iteration (part2/2b/main.py:101-106)
+    and moves nothing."""
+    from distributed_machine_learning_amd.cli import main
+    res = main(["--iters", "6", "--batch-size", "32", "--train-size", "512", "--test-size", "64",
+                "--no-summary", "--no-eval", "--report-comm-volume", "--master-ip",
+                "127.0.0.1:29641", "--rank", "0", "--num-nodes", "1"],
+               part="part2b")
+    out = capsys.readouterr().out
+    assert "communication volume over 6 iterations: TX 0.000 GB, RX 0.000 GB" in out
+    vol = res["comm_volume"]
+    assert vol["calls"]["all_reduce"] >= 6 * 18 and vol["calls"]["gather"] == 0
+    assert vol["payload_bytes"]["all_reduce"] >= 6 * 9_225_610 * 4
+
+
 def test_bench_prints_one_json_record():
     """bench.py's stdout is exactly one JSON line with the fields the harness reads - also when
     a communicator (and with it RCCL's start-up banner) is in play."""

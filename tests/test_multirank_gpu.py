@@ -170,6 +170,21 @@ def test_bench_self_launches_two_ranks_and_proves_it(mode):
     assert plan["mode"] == {"part2a": "gather_scatter", "part2b": "all_reduce", "part3": "ddp"}[mode]
     if mode == "part3":
         assert len(plan["buckets_mb"]) >= 3 and plan["inline_last_bucket"] is False
+    # what rank 0 moved per step, from the collectives issued inside the measured region: with
+    # two ranks the root of gather/scatter receives and sends one model of gradients, a ring
+    # all-reduce moves 2 (W-1)/W = 1 model each way (the report's per-node byte counts,
+    # /root/reference/group25.pdf p4 and p6, follow the same arithmetic at four nodes)
+    vol = rec["comm_bytes_per_step"]
+    model_bytes = 9_225_610 * 4
+    if mode == "part3":                 # + BatchNorm weights, + running statistics in a bucket
+        model_bytes += (2 * 2752 + 2 * 2752) * 4
+    assert vol["tx"] == pytest.approx(model_bytes, rel=1e-3)
+    assert vol["rx"] == pytest.approx(model_bytes, rel=1e-3)
+    per_step = {k: v / 4 for k, v in vol["calls"].items()}
+    if mode == "part2a":
+        assert per_step["gather"] == 18 and per_step["scatter"] == 18
+    elif mode == "part2b":
+        assert per_step["all_reduce"] == pytest.approx(18, abs=1)     # + the two barriers' tokens
 
 
 def test_bench_one_rank_rccl_record_fields():

@@ -131,3 +131,33 @@ def test_tail_bucket_cap_splits_only_the_last_bucket():
     covered = sorted(i for a, b in split for i in range(a, b))
     assert covered == list(range(len(sizes)))
     assert cap_tail_bucket(buckets, sizes, 0) == buckets
+
+
+def test_link_byte_model_reproduces_the_reports_network_volumes():
+    """The reference's report plots per-node network bytes over its 40 iterations on four nodes
+    (/root/reference/group25.pdf p4 fig 1-2: node 0 ~4.4e9 each way and the others ~1.5e9 with
+    gather/scatter; p6 fig 3-4: ~2.2e9 per node with all_reduce).  The communicator's accounting
+    (csrc/comm/rccl_comm.cpp: link_bytes) gives those numbers for VGG-11's 18 gradient tensors."""
+    C = native.lib()
+    ALL_REDUCE, BROADCAST, GATHER, SCATTER = 0, 1, 2, 3
+    model = 9_225_610 * 4
+    iters, world = 40, 4
+
+    def total(kinds, is_root):
+        tx = rx = 0
+        for k in kinds:
+            t, r = C.link_bytes(k, model, world, is_root)
+            tx, rx = tx + t, rx + r
+        return tx * iters, rx * iters
+
+    root_tx, root_rx = total((GATHER, SCATTER), True)
+    other_tx, other_rx = total((GATHER, SCATTER), False)
+    assert root_tx == root_rx == 3 * model * iters          # 4.43e9
+    assert 4.3e9 < root_tx < 4.5e9
+    assert other_tx == other_rx == model * iters            # 1.48e9
+    assert 1.4e9 < other_tx < 1.6e9
+    ar_tx, ar_rx = total((ALL_REDUCE,), False)
+    assert ar_tx == ar_rx and 2.1e9 < ar_tx < 2.3e9         # 2 * 3/4 of the model per iteration
+    assert C.link_bytes(ALL_REDUCE, model, 1, True) == (0, 0)
+    assert C.link_bytes(BROADCAST, 100, 4, True) == (100, 0)
+    assert C.link_bytes(BROADCAST, 100, 4, False) == (0, 100)
