@@ -74,17 +74,39 @@ BucketReducer::BucketReducer(Comm* comm, float* flat_grads, std::vector<Slice> s
         check_hip(hipEventCreateWithFlags(&ready_[i], ready_flags), "hipEventCreate");
         check_hip(hipEventCreateWithFlags(&done_[i], done_flags), "hipEventCreate");
     }
+    // A stream that waits for an EVENT of another queue costs the step ~6.5 us per bucket on
+    // MI355X / ROCm 7 (measured at one rank by leaving the wait out: the marker alone costs
+    // 1.7 us, marker + wait 8 us, tools/ab_reducer_probe.sh).  Where the device can wait for a
+    // value in memory, a bucket departs through a flag word instead: a one-wave kernel behind
+    // the bucket's last gradient kernel raises it - every earlier kernel of that queue has then
+    // completed and written its results back, which is all the local RCCL kernel and its peers
+    // (who read device memory over xGMI, never this GPU's L2) need - and the communication
+    // stream holds a wait-value packet.  DML_REDUCER_HANDOFF=event keeps the event pair.
+    int can_wait_value = 0, device = 0;
+    if (!serialize_ && hipGetDevice(&device) == hipSuccess)
+        (void)hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device);
+    const char* mode = getenv("DML_REDUCER_HANDOFF");
+    by_value_ = can_wait_value && !(mode && !strcmp(mode, "event"));
+    if (by_value_) {
+        // (word b: bucket b's gradients are complete; word n + b: its all-reduce is complete)
+        const size_t bytes = 2 * slices_.size() * sizeof(unsigned);
+        check_hip(hipMalloc((void**)&ready_flags_, bytes), "hipMalloc(bucket flags)");
+        check_hip(hipMemset(ready_flags_, 0, bytes), "hipMemset(bucket flags)");
+        check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(bucket flags)");
+    }
 }
 
 BucketReducer::~BucketReducer() {
     for (auto e : ready_) (void)hipEventDestroy(e);
     for (auto e : done_) (void)hipEventDestroy(e);
     if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
+    if (ready_flags_) (void)hipFree(ready_flags_);
 }
 
 void BucketReducer::begin_step() {
     launched_.assign(slices_.size(), 0);
     last_ready_ = -1;
+    ++step_seq_;
 }
 
 void BucketReducer::bucket_ready(int b, hipStream_t compute,
@@ -101,12 +123,39 @@ void BucketReducer::bucket_ready(int b, hipStream_t compute,
         if (after) after(compute);
         return;
     }
+    // (measurement knob, one rank only: which part of a bucket's departure costs the step time)
+    static const char* probe = getenv("DML_REDUCER_PROBE");
+    if (probe && comm_->world_size() == 1) {
+        if (!strcmp(probe, "skip")) return;                          // no event, no hop
+        if (!strcmp(probe, "marker")) {                              // the marker alone
+            check_hip(hipEventRecord(ready_[b], compute), "hipEventRecord(ready)");
+            return;
+        }
+        if (!strcmp(probe, "nodone")) {                              // marker + wait, no "done"
+            check_hip(hipEventRecord(ready_[b], compute), "hipEventRecord(ready)");
+            check_hip(hipStreamWaitEvent(comm_stream_, ready_[b], 0), "hipStreamWaitEvent(comm)");
+            return;
+        }
+    }
     last_ready_ = b;
-    check_hip(hipEventRecord(ready_[b], compute), "hipEventRecord(ready)");
-    check_hip(hipStreamWaitEvent(comm_stream_, ready_[b], 0), "hipStreamWaitEvent(comm)");
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(compute, &capturing);
+    if (by_value_ && capturing == hipStreamCaptureStatusNone) {
+        enqueue_flag_raise(ready_flags_ + b, step_seq_, compute);
+        check_hip(hipStreamWaitValue32(comm_stream_, ready_flags_ + b, step_seq_,
+                                       hipStreamWaitValueGte, 0xffffffffu),
+                  "hipStreamWaitValue32(comm)");
+    } else {
+        check_hip(hipEventRecord(ready_[b], compute), "hipEventRecord(ready)");
+        check_hip(hipStreamWaitEvent(comm_stream_, ready_[b], 0), "hipStreamWaitEvent(comm)");
+    }
     reduce_slice(b, comm_stream_);
     if (after) after(comm_stream_);
-    check_hip(hipEventRecord(done_[b], comm_stream_), "hipEventRecord(done)");
+    done_by_value_ = by_value_ && capturing == hipStreamCaptureStatusNone;
+    if (done_by_value_)
+        enqueue_flag_raise(ready_flags_ + slices_.size() + b, step_seq_, comm_stream_);
+    else
+        check_hip(hipEventRecord(done_[b], comm_stream_), "hipEventRecord(done)");
 }
 
 void BucketReducer::set_bf16_payload(bf16_raw* wire) {
@@ -146,8 +195,14 @@ void BucketReducer::wait_all(hipStream_t compute) {
                                    std::to_string(b) + " never marked ready");
     // The communication stream runs the buckets in the order they were marked ready, so the
     // event of the most recent one covers them all: one cross-stream wait, not one per bucket.
-    if (!serialize_ && last_ready_ >= 0)
-        check_hip(hipStreamWaitEvent(compute, done_[last_ready_], 0), "hipStreamWaitEvent(compute)");
+    if (!serialize_ && last_ready_ >= 0) {
+        if (done_by_value_)
+            check_hip(hipStreamWaitValue32(compute, ready_flags_ + slices_.size() + last_ready_,
+                                           step_seq_, hipStreamWaitValueGte, 0xffffffffu),
+                      "hipStreamWaitValue32(compute)");
+        else
+            check_hip(hipStreamWaitEvent(compute, done_[last_ready_], 0), "hipStreamWaitEvent(compute)");
+    }
     if (buffers_staged_) {
         buffers_staged_ = false;
         buffers_pending_ = true;        // the staging area now holds rank 0's values everywhere
@@ -346,6 +401,8 @@ void bind_comm(py::module_& m) {
             r.set_bf16_payload((bf16_raw*)wire);
         })
         .def_property("inline_last", &BucketReducer::inline_last, &BucketReducer::set_inline_last)
+        .def_property_readonly("departure_mode",
+                               [](BucketReducer& r) { return std::string(r.departure_mode()); })
         .def_property_readonly("comm_stream",
                                [](BucketReducer& r) { return (uintptr_t)r.comm_stream(); });
 }

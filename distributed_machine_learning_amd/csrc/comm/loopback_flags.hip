@@ -37,6 +37,12 @@ void loopback_enqueue_signal(unsigned* flag, unsigned value, hipStream_t stream)
     hipLaunchKernelGGL(loopback_signal_kernel, dim3(1), dim3(64), 0, stream, flag, value);
 }
 
+// The same one-wave kernel serves the bucket reducer's departures (flag word in device memory,
+// consumer = a wait-value packet on another queue of this GPU).
+void enqueue_flag_raise(unsigned* flag, unsigned value, hipStream_t stream) {
+    hipLaunchKernelGGL(loopback_signal_kernel, dim3(1), dim3(64), 0, stream, flag, value);
+}
+
 void loopback_enqueue_wait(const unsigned* flag, unsigned value, unsigned* timed_out,
                            long long max_ticks, hipStream_t stream) {
     hipLaunchKernelGGL(loopback_wait_kernel, dim3(1), dim3(64), 0, stream, flag, value, timed_out,

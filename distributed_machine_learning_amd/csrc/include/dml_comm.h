@@ -202,6 +202,8 @@ class LoopbackComm : public Comm {
 
 // stream-side flag kernels of the loopback transport (loopback_flags.hip)
 void loopback_enqueue_signal(unsigned* flag, unsigned value, hipStream_t stream);
+// "everything enqueued on `stream` before this has completed": raises *flag to `value`
+void enqueue_flag_raise(unsigned* flag, unsigned value, hipStream_t stream);
 void loopback_enqueue_wait(const unsigned* flag, unsigned value, unsigned* timed_out,
                            long long max_ticks, hipStream_t stream);
 
@@ -274,6 +276,8 @@ class BucketReducer {
                       bool in_line = false);
     void wait_all(hipStream_t compute);
     hipStream_t comm_stream() const { return comm_stream_; }
+    // "value": flag word + wait-value packet, "event": event pair
+    const char* departure_mode() const { return by_value_ ? "value" : "event"; }
     // Send gradients as bf16: `wire` is a bf16 buffer as long as the flat gradient buffer (same
     // element offsets).  A bucket is rounded into it, summed there and widened back into the
     // fp32 gradients, all on the stream that runs its collective.  nullptr: fp32 on the wire.
@@ -307,6 +311,12 @@ class BucketReducer {
     uint16_t* wire_ = nullptr;
     hipStream_t comm_stream_ = nullptr;
     std::vector<hipEvent_t> ready_, done_;
+    // Departures through flag words instead of the "ready" event pair (see bucket_ready): word b
+    // is raised to the step's sequence number by a one-wave kernel behind bucket b's gradients.
+    unsigned* ready_flags_ = nullptr;
+    unsigned step_seq_ = 0;
+    bool by_value_ = false;
+    bool done_by_value_ = false;            // how the most recent bucket reports completion
     std::vector<char> launched_;
     int last_ready_ = -1;
     float* buffers_ = nullptr;

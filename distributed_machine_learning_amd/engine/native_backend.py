@@ -229,6 +229,7 @@ class NativeBackend:
         if self.reducer is not None:
             plan["buckets_mb"] = [round(c * 4 / (1 << 20), 3) for _, c in self._bucket_slices]
             plan["inline_last_bucket"] = bool(self.reducer.inline_last)
+            plan["bucket_departure"] = self.reducer.departure_mode
             plan["wire_dtype"] = self.cfg.grad_comm_dtype
         if self.manual is not None:
             plan["collectives_per_step"] = len(self.slots) * (2 if self.sync_name ==
