@@ -291,9 +291,12 @@ void VggEngine::set_wgrad_overlap(bool on, int group, hipStream_t compute_stream
         (void)hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device);
         const char* mode = getenv("DML_HANDOFF");
         value_hand_off_ = can_wait_value && !(mode && !strcmp(mode, "event"));
+        join_by_value_ = !(getenv("DML_JOIN") && !strcmp(getenv("DML_JOIN"), "event"));
         if (value_hand_off_) {
-            check_hip(hipMalloc((void**)&hand_off_flags_, convs_.size() * sizeof(unsigned)), "hipMalloc(hand-off flags)");
-            check_hip(hipMemset(hand_off_flags_, 0, convs_.size() * sizeof(unsigned)), "hipMemset(hand-off flags)");
+            // one word per layer + one for the side stream's "done with this backward pass"
+            const size_t bytes = (convs_.size() + 1) * sizeof(unsigned);
+            check_hip(hipMalloc((void**)&hand_off_flags_, bytes), "hipMalloc(hand-off flags)");
+            check_hip(hipMemset(hand_off_flags_, 0, bytes), "hipMemset(hand-off flags)");
             check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(hand-off flags)");
         }
         for (hipEvent_t& e : hand_off_)
@@ -350,9 +353,17 @@ void VggEngine::join_wgrad_stream(hipStream_t stream) {
     // side_done_ was recorded right behind the side stream's last launch (see backward), so
     // that it has usually fired by now and this wait costs the main stream nothing; recording
     // it here would send a fresh marker through the other queue (~10 us) on the critical path
-    if (!side_done_recorded_)
-        check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
-    check_hip(hipStreamWaitEvent(stream, side_done_, 0), "hipStreamWaitEvent(side done)");
+    if (side_done_by_value_) {
+        // (a queue waiting for another queue's EVENT costs ~6 us; for a word in memory, ~3)
+        check_hip(hipStreamWaitValue32(stream, hand_off_flags_ + convs_.size(), backward_seq_,
+                                       hipStreamWaitValueGte, 0xffffffffu),
+                  "hipStreamWaitValue32(side done)");
+    } else {
+        if (!side_done_recorded_)
+            check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
+        check_hip(hipStreamWaitEvent(stream, side_done_, 0), "hipStreamWaitEvent(side done)");
+    }
+    side_done_by_value_ = false;
     side_busy_ = false;
     side_done_recorded_ = false;
 }
@@ -592,6 +603,7 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     wgrad_queue_.clear();       // (left-overs of a step that threw)
     wgrad_sums_.n = 0;
     side_done_recorded_ = false;
+    side_done_by_value_ = false;
     // (a captured graph keeps the event pair: its edges come from the capture)
     const bool by_value = side && value_hand_off_ && !capturing_;
     if (by_value) ++backward_seq_;
@@ -749,7 +761,12 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                 updated_above = i;
             }
             if (i <= 1) {                   // the side stream's last work of this step
-                check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
+                if (by_value && join_by_value_) {
+                    enqueue_flag_raise(hand_off_flags_ + nconv, backward_seq_, wgrad_stream_);
+                    side_done_by_value_ = true;
+                } else {
+                    check_hip(hipEventRecord(side_done_, wgrad_stream_), "hipEventRecord(side done)");
+                }
                 side_done_recorded_ = true;
             }
         }

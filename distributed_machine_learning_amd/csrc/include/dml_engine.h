@@ -207,6 +207,8 @@ class VggEngine {
     unsigned* hand_off_flags_ = nullptr;
     unsigned backward_seq_ = 0;
     bool value_hand_off_ = false;
+    bool join_by_value_ = true;             // the side stream's "done" through a flag word as well
+    bool side_done_by_value_ = false;       // ... and this backward pass has raised it that way
     std::vector<int> wgrad_queue_;          // layers whose gradient is ready, wgrad not yet launched
     bool tuned_wgrad_splits_ = true;        // use conv3x3_wgrad_tuned_splits where it has an entry
     // tuning (DML_DGRAD_PLANS): backward-data plan {bm, bn, splits, pm, waves} per conv layer, bm 0 = default
