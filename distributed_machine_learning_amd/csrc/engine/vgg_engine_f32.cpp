@@ -147,7 +147,8 @@ void VggEngineF32::set_wgrad_overlap(bool on, hipStream_t compute_stream) {
         const char* mode = getenv("DML_HANDOFF");
         value_hand_off_ = can_wait_value && !(mode && !strcmp(mode, "event"));
         if (value_hand_off_) {
-            const size_t bytes = lay_.convs.size() * sizeof(unsigned);
+            // one word per layer + three for the side stream's joins (see side_raise)
+            const size_t bytes = (lay_.convs.size() + 3) * sizeof(unsigned);
             check_hip(hipMalloc((void**)&hand_off_flags_, bytes), "hipMalloc(hand-off flags)");
             check_hip(hipMemset(hand_off_flags_, 0, bytes), "hipMemset(hand-off flags)");
             check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(hand-off flags)");
@@ -184,9 +185,28 @@ void VggEngineF32::flush_sums(hipStream_t stream) {
     sums_.n = 0;
 }
 
+// The side stream tells the main stream "done up to here": through a flag word raised by a
+// one-wave kernel and a wait-value packet where the device has them (a queue that waits for
+// another queue's EVENT pays ~6 us for it, for a word in memory ~3), else through the event.
+void VggEngineF32::side_raise(int word, hipEvent_t event) {
+    if (value_hand_off_)
+        enqueue_flag_raise(hand_off_flags_ + lay_.convs.size() + word, ++join_seq_[word], side_);
+    else
+        check_hip(hipEventRecord(event, side_), "hipEventRecord(side)");
+}
+
+void VggEngineF32::main_await(int word, hipEvent_t event, hipStream_t stream) {
+    if (value_hand_off_)
+        check_hip(hipStreamWaitValue32(stream, hand_off_flags_ + lay_.convs.size() + word,
+                                       join_seq_[word], hipStreamWaitValueGte, 0xffffffffu),
+                  "hipStreamWaitValue32(side)");
+    else
+        check_hip(hipStreamWaitEvent(stream, event, 0), "hipStreamWaitEvent(side)");
+}
+
 void VggEngineF32::join_repack(hipStream_t stream) {
     if (!repack_pending_) return;
-    check_hip(hipStreamWaitEvent(stream, repack_done_, 0), "hipStreamWaitEvent(repack)");
+    main_await(kJoinRepack, repack_done_, stream);
     repack_pending_ = false;
 }
 
@@ -228,7 +248,7 @@ void VggEngineF32::clear_split_outputs(int batch, bool training, hipStream_t str
         check_hip(hipEventRecord(fwd_begin_, stream), "hipEventRecord(forward begin)");
         check_hip(hipStreamWaitEvent(side_, fwd_begin_, 0), "hipStreamWaitEvent(forward begin)");
         zero_buffers(jobs, side_);
-        check_hip(hipEventRecord(cleared_, side_), "hipEventRecord(cleared)");
+        side_raise(kJoinCleared, cleared_);
         clear_pending_ = true;
     } else {
         zero_buffers(jobs, stream);
@@ -237,7 +257,7 @@ void VggEngineF32::clear_split_outputs(int batch, bool training, hipStream_t str
 
 void VggEngineF32::join_clear(hipStream_t stream) {
     if (!clear_pending_) return;
-    check_hip(hipStreamWaitEvent(stream, cleared_, 0), "hipStreamWaitEvent(cleared)");
+    main_await(kJoinCleared, cleared_, stream);
     clear_pending_ = false;
 }
 
@@ -422,15 +442,15 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
         // were written on the main stream before grad_ready_[i]); the last one only after the side
         // stream's share of it is complete
         if (overlap_ && i == 0 && reducer_ && !buckets_by_layer_[0].empty()) {
-            check_hip(hipEventRecord(side_done_, side_), "hipEventRecord(side done)");
-            check_hip(hipStreamWaitEvent(stream, side_done_, 0), "hipStreamWaitEvent(side done)");
+            side_raise(kJoinSideDone, side_done_);
+            main_await(kJoinSideDone, side_done_, stream);
         }
         fire_buckets(i, wstream);
     }
     flush_sums(stream);
     if (overlap_) {
-        check_hip(hipEventRecord(side_done_, side_), "hipEventRecord(side done)");
-        check_hip(hipStreamWaitEvent(stream, side_done_, 0), "hipStreamWaitEvent(side done)");
+        side_raise(kJoinSideDone, side_done_);
+        main_await(kJoinSideDone, side_done_, stream);
     }
 }
 
@@ -465,7 +485,7 @@ void VggEngineF32::optimizer_step(float lr, float momentum, float weight_decay, 
             const ParamLayout::Conv& c = lay_.convs[i];
             repack_dgrad_weights_f32(params_ + c.w_off, arena_ + buf_[i].wd_off, c.cout, c.cin, side_);
         }
-        check_hip(hipEventRecord(repack_done_, side_), "hipEventRecord(repack)");
+        side_raise(kJoinRepack, repack_done_);
         repack_pending_ = true;
     } else {
         refresh_weights(stream);

@@ -305,6 +305,11 @@ class VggEngineF32 {
     unsigned* hand_off_flags_ = nullptr;
     unsigned backward_seq_ = 0;
     bool value_hand_off_ = false;
+    // ... and the side stream's three joins with the main stream
+    enum { kJoinSideDone = 0, kJoinRepack = 1, kJoinCleared = 2 };
+    unsigned join_seq_[3] = {0, 0, 0};
+    void side_raise(int word, hipEvent_t event);
+    void main_await(int word, hipEvent_t event, hipStream_t stream);
     hipEvent_t side_done_ = nullptr, updated_ = nullptr, repack_done_ = nullptr;
     bool repack_pending_ = false;           // weight layouts of the last update still on the side stream
     void join_repack(hipStream_t stream);
