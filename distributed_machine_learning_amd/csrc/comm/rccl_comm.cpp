@@ -14,6 +14,7 @@
 #include <stdexcept>
 
 #include "dml_comm.h"
+#include "dml_kernels.h"
 
 namespace dml {
 
@@ -126,9 +127,21 @@ void RcclComm::group_end() {
     if (group_depth_ == 0) {
         // the grouped transfers are enqueued now; the root's own copies follow them in stream
         // order (they touch buffers no transfer of the group reads or writes)
-        for (const SelfCopy& c : deferred_copies_)
-            check_hip(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, c.stream),
-                      "hipMemcpyAsync(self copy)");
+        // ... batched: one launch per run of copies on the same stream instead of one copy
+        // kernel per tensor
+        CopyJobs jobs;
+        hipStream_t on = nullptr;
+        auto flush = [&]() {
+            if (jobs.n) copy_batch(jobs, on);
+            jobs.n = 0;
+        };
+        for (const SelfCopy& c : deferred_copies_) {
+            if (jobs.n && (c.stream != on || jobs.n == CopyJobs::kMax)) flush();
+            on = c.stream;
+            jobs.dst[jobs.n] = c.dst; jobs.src[jobs.n] = c.src; jobs.bytes[jobs.n] = c.bytes;
+            ++jobs.n;
+        }
+        flush();
         deferred_copies_.clear();
     }
 }

@@ -361,6 +361,15 @@ void conv3x3_igemm_f32(const float* x, const float* w, float* y, const float* bi
 // 2 when the default plan divides the taps of a position between two blocks that meet in y through
 // atomics - y must then be zero before the launch (the launcher clears it unless pre_zeroed)
 int conv3x3_igemm_f32_tap_splits(ConvShape s, ConvEpilogue epi);
+// several device-to-device copies in one launch (any alignment; 16-byte vectors when it allows)
+struct CopyJobs {
+    static constexpr int kMax = 24;
+    int n = 0;
+    void* dst[kMax];
+    const void* src[kMax];
+    size_t bytes[kMax];
+};
+void copy_batch(const CopyJobs& jobs, hipStream_t stream);
 // several fp32 buffers cleared in one launch (counts in floats, multiples of 4, 16-byte aligned)
 struct ZeroJobs {
     static constexpr int kMax = 16;

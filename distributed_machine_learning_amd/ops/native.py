@@ -549,6 +549,22 @@ def sum_slabs_(slabs: torch.Tensor) -> None:
     lib().sum_slabs(slabs.data_ptr(), slabs.shape[0], slabs.shape[1], _stream())
 
 
+def copy_batch_(pairs) -> None:
+    """``dst.copy_(src)`` for every ``(dst, src)`` pair of contiguous device tensors with equal
+    byte sizes, in one kernel launch (per 24 pairs)."""
+    items = []
+    for dst, src in pairs:
+        if not (dst.is_cuda and src.is_cuda and dst.is_contiguous() and src.is_contiguous()):
+            raise ValueError("copy_batch_: contiguous device tensors only")
+        nbytes = dst.numel() * dst.element_size()
+        if nbytes != src.numel() * src.element_size():
+            raise ValueError("copy_batch_: byte sizes differ")
+        if nbytes:
+            items.append((dst.data_ptr(), src.data_ptr(), nbytes))
+    if items:
+        lib().copy_batch(items, _stream())
+
+
 def fill_uniform_(t: torch.Tensor, seed: int, scale: float = 1.0) -> torch.Tensor:
     _req(t, torch.bfloat16, "t")
     lib().fill_uniform_bf16(t.data_ptr(), t.numel(), seed, scale, _stream())

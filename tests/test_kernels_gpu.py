@@ -584,6 +584,31 @@ def test_column_sum_and_slab_sum():
     assert torch.allclose(slabs[0], ref, rtol=1e-6, atol=1e-5)
 
 
+def test_copy_batch_copies_every_job_and_nothing_else():
+    """One launch copies many tensors (the gather / scatter root's own 18 gradient tensors):
+    VGG-11's tensor sizes, plus odd sizes and misaligned views for the narrow paths."""
+    n = native()
+    sizes = [1728, 64, 73728, 128, 294912, 256, 589824, 256, 1179648, 512, 2359296, 512,
+             5120, 10, 7, 1, 33]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    pairs, checks = [], []
+    for i, sz in enumerate(sizes):
+        src = torch.randn(sz + 2, generator=g).to(DEV)
+        dst = torch.full((sz + 4,), -7.0, device=DEV)
+        off = 1 if i % 3 == 2 else 0                      # 4-byte aligned only
+        pairs.append((dst[1 + off:1 + off + sz], src[off:off + sz]))
+        checks.append((dst, src, off, sz))
+    raw = torch.arange(0, 251, dtype=torch.uint8, device=DEV)      # byte path, odd length
+    raw_dst = torch.zeros(260, dtype=torch.uint8, device=DEV)
+    pairs.append((raw_dst[3:3 + 251], raw))
+    n.copy_batch_(pairs)
+    torch.cuda.synchronize()
+    for dst, src, off, sz in checks:
+        assert torch.equal(dst[1 + off:1 + off + sz], src[off:off + sz])
+        assert float(dst[off]) == -7.0 and float(dst[1 + off + sz]) == -7.0    # borders intact
+    assert torch.equal(raw_dst[3:254], raw) and int(raw_dst[:3].sum()) == 0 and int(raw_dst[254:].sum()) == 0
+
+
 def test_augment_kernel_matches_reference_transform():
     from distributed_machine_learning_amd.data import synthetic_cifar
     from distributed_machine_learning_amd.data.transforms import (_augment_reference,
