@@ -235,6 +235,9 @@ class ManualSync {
     int root_;
     float* slabs_;
     size_t stride_;
+    bool in_place_ = false;
+  public:
+    bool in_place() const { return in_place_; }
 };
 
 // ------------------------------------------------------------------- bucket planning

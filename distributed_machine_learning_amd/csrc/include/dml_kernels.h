@@ -315,6 +315,9 @@ void nchw_f32_to_nhwc_bf16(const float* x, bf16_raw* out, int batch, int c, int 
 void nhwc_bf16_to_nchw_f32(const bf16_raw* x, float* out, int batch, int c, int hw, hipStream_t s);
 // slabs[0][i] += slabs[1][i] + ... + slabs[w-1][i]   (root-side reduction of gather/scatter)
 void sum_slabs(float* slabs, int world, size_t n, hipStream_t stream);
+// dst[i] += slabs[0][i] + ... + slabs[k-1][i], slab r at slabs + r * stride, i < n
+void sum_slabs_into(float* dst, const float* slabs, int k, size_t stride, size_t n,
+                    hipStream_t stream);
 // fill a bf16 buffer with uniform values in [-1, 1) from a counter hash (tests / benches)
 void fill_uniform_bf16(bf16_raw* out, size_t n, uint32_t seed, float scale, hipStream_t stream);
 

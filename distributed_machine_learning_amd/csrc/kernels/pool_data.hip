@@ -345,6 +345,42 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(float4* __restrict__ sla
     }
 }
 
+// dst[i] += slabs[0][i] + ... + slabs[k-1][i]: the root's own gradients are the first addend and
+// stay where they are (same order of additions as sum_slabs on a landing area that holds the
+// root's copy in slab 0)
+__global__ __launch_bounds__(256) void sum_slabs_into_kernel(float* __restrict__ dst,
+                                                             const float* __restrict__ slabs,
+                                                             int k, size_t stride, size_t n) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n / 4;
+    for (size_t i = tid; i < n4; i += step) {
+        float4 a = ((const float4*)dst)[i];
+        for (int r = 0; r < k; ++r) {
+            const float4 v = ((const float4*)(slabs + (size_t)r * stride))[i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        ((float4*)dst)[i] = a;
+    }
+    for (size_t i = n4 * 4 + tid; i < n; i += step) {       // at most three elements
+        float a = dst[i];
+        for (int r = 0; r < k; ++r) a += slabs[(size_t)r * stride + i];
+        dst[i] = a;
+    }
+}
+
+void sum_slabs_into(float* dst, const float* slabs, int k, size_t stride, size_t n,
+                    hipStream_t stream) {
+    if (k <= 0 || n == 0) return;
+    if (((uintptr_t)dst & 15) || ((uintptr_t)slabs & 15) || stride % 4)
+        throw std::invalid_argument("sum_slabs_into: 16-byte aligned buffers, stride % 4 == 0");
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sum_slabs_into_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst,
+                       slabs, k, stride, n);
+}
+
 // Batched form for the wgrad partial results: job j owns blocks [block_start[j],
 // block_start[j+1]), a thread sums one float4 column over the job's splits with eight loads in
 // flight (the kernel is a pure stream: splits * count floats in, count out).
