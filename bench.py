@@ -63,14 +63,16 @@ def parse(argv=None):
     ap.add_argument("--backend", choices=("native", "torch"), default="native")
     ap.add_argument("--dtype", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU)")
-    ap.add_argument("--bucket-cap-mb", type=float, default=10.0,
-                    help="gradient bucket size.  10 MiB (first bucket included) cuts VGG-11's "
-                         "37 MB of gradients into {fc1, conv8, conv7} - on the wire a quarter of "
-                         "the way into backward -, {conv6, conv5} and {conv4 .. conv1}, which "
-                         "--tail-bucket-cap-mb splits again.  Buckets leave from the weight-"
-                         "gradient stream, so an extra bucket costs the compute stream nothing "
-                         "(measured at one rank: 2 .. 24 MiB caps are within 2 %% of each other); "
-                         "smaller buckets put the first bytes on the wire earlier")
+    ap.add_argument("--bucket-cap-mb", type=float, default=4.5,
+                    help="gradient bucket size.  A bucket closes once it has reached the cap; "
+                         "4.5 MiB gives every large layer of VGG-11 a bucket of its own - {fc1, "
+                         "conv8}, {conv7}, {conv6} (9 MB each), {conv5} (4.5 MB) - and leaves "
+                         "{conv4 .. conv1}, which --tail-bucket-cap-mb splits again, so the first "
+                         "bytes are on the wire as soon as the first weight gradient exists and "
+                         "nothing waits for a neighbour layer.  Buckets depart from the weight-"
+                         "gradient stream through flag words and cost the compute side about a "
+                         "microsecond each (one rank, multi-rank schedule: 3 buckets 0.6266, 4 "
+                         "buckets 0.6265, 6 buckets 0.627, 7 buckets 0.629 ms per step)")
     ap.add_argument("--first-bucket-cap-mb", type=float, default=None,
                     help="defaults to --bucket-cap-mb")
     ap.add_argument("--tail-bucket-cap-mb", type=float, default=1.0,
