@@ -143,8 +143,8 @@ def test_mismatched_replicas_fail_loudly(tmp_path):
     assert not os.path.exists(out + ".rank0")
 
 
-def _bench(args, timeout=420):
-    env = dict(os.environ)
+def _bench(args, timeout=420, extra_env=None):
+    env = dict(os.environ, **(extra_env or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args,
@@ -170,6 +170,8 @@ def test_bench_self_launches_two_ranks_and_proves_it(mode):
     assert plan["mode"] == {"part2a": "gather_scatter", "part2b": "all_reduce", "part3": "ddp"}[mode]
     if mode == "part3":
         assert len(plan["buckets_mb"]) >= 3 and plan["inline_last_bucket"] is False
+        assert plan["bucket_departure"] == "value"      # MI355X / ROCm 7 can wait for a value
+    assert rec["extras_error"] is None
     # what rank 0 moved per step, from the collectives issued inside the measured region: with
     # two ranks the root of gather/scatter receives and sends one model of gradients, a ring
     # all-reduce moves 2 (W-1)/W = 1 model each way (the report's per-node byte counts,
@@ -185,6 +187,21 @@ def test_bench_self_launches_two_ranks_and_proves_it(mode):
         assert per_step["gather"] == 18 and per_step["scatter"] == 18
     elif mode == "part2b":
         assert per_step["all_reduce"] == pytest.approx(18, abs=1)     # + the two barriers' tokens
+
+
+def test_bench_two_ranks_with_every_fallback_forced():
+    """A device without wait-value support (or a graph capture) falls back to event pairs for the
+    hand-offs, the joins and the bucket departures, and the gather/scatter root can use a landing
+    slab for its own copy: those paths must keep working."""
+    env = {"DML_HANDOFF": "event", "DML_REDUCER_HANDOFF": "event", "DML_JOIN": "event",
+           "DML_EVENT_SCOPE": "system", "DML_GATHER_IN_PLACE": "0"}
+    for mode in ("part3", "part2a"):
+        rec = _bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--windows", "1", "--mode", mode,
+                      "--batch-size", "32", "--transport", "loopback"], extra_env=env)
+        assert rec["params_in_sync"] is True and rec["rccl_nranks"] == 2
+        assert rec["extras_error"] is None
+        if mode == "part3":
+            assert rec["config"]["sync_plan"]["bucket_departure"] == "event"
 
 
 def test_bench_one_rank_rccl_record_fields():
