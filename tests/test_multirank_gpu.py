@@ -72,6 +72,18 @@ def test_two_ranks_mean_match_single_process_global_batch(tmp_path, sync):
 
 
 @pytest.mark.parametrize("sync", ["gather_scatter", "ddp"])
+def test_four_ranks_mean_match_single_process_global_batch(tmp_path, sync):
+    """The reference's own world size (four nodes, /root/reference/group25.pdf p1): four ranks of
+    4 images reproduce the single-process run on the 16-image global batch."""
+    single = _run(tmp_path, "single", 1, ["--sync", "none", "--batch-size", "16", "--iters", "3"])[0]
+    ranks = _run(tmp_path, sync, 4, ["--sync", sync, "--grad-reduce", "mean", "--batch-size", "4",
+                                     "--iters", "3", "--bucket-cap-mb", "4"])
+    for r in ranks[1:]:
+        assert _same(ranks[0], r)
+    assert _rel(ranks[0], single) < 1e-4
+
+
+@pytest.mark.parametrize("sync", ["gather_scatter", "ddp"])
 def test_fp32_engine_two_ranks_match_single_process(tmp_path, sync):
     """The fp32 engine (the reference's precision) under the same protocol."""
     extra = ["--batch-norm"] if sync == "ddp" else []
