@@ -116,3 +116,30 @@ def test_cpu_device_has_no_multi_rank_transport():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert r.returncode != 0
     assert "only transport is RCCL" in r.stderr
+
+
+def test_scaling_study_table():
+    """tools/scaling_study.py: efficiency is per-GPU throughput against the mode's first row, the
+    reference column comes from the report's published s/iter."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scaling_study",
+                                                  os.path.join(ROOT, "tools", "scaling_study.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def rec(n, ms, overlap=None, vol=None, sync=None):
+        return {"n_gpus": n, "ms_per_step": ms, "s_per_iter": ms / 1e3,
+                "value": 256 * n / (ms / 1e3), "params_in_sync": sync,
+                "comm_bytes_per_step": vol,
+                "config": {"mode": "part3", "overlap": overlap}}
+
+    text = mod.table([rec(1, 0.6), rec(4, 0.75, {"exposed_comm_ms": 0.15, "overlap_fraction": 0.5},
+                                       {"tx": 55_400_000, "rx": 55_400_000}, True)])
+    lines = text.splitlines()
+    assert len(lines) == 4
+    one, four = lines[2].split(), lines[3].split()
+    assert one[0] == "part3" and one[1] == "1" and one[4] == "100.0%"
+    assert four[1] == "4" and four[4] == "80.0%"          # 0.6 / 0.75
+    assert "0.150 ms" in lines[3] and "50 %" in lines[3] and "55.4" in lines[3] and "yes" in lines[3]
+    assert "0.838" in lines[3]                            # the report's part3 time at four nodes
+    assert lines[3].rstrip().endswith("1118x")            # 0.83813 s against 0.75 ms

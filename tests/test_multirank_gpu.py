@@ -223,3 +223,21 @@ def test_bench_one_rank_rccl_record_fields():
     assert rec["config"]["overlap"] is not None
     assert rec["windows"]["min_ms_per_step"] <= rec["windows"]["median_ms_per_step"]
     assert rec["config"]["sync_plan"]["inline_last_bucket"] is True
+
+
+def test_scaling_study_runs_one_and_two_ranks(tmp_path):
+    """tools/scaling_study.py drives bench.py over GPU counts and modes (here: the test transport,
+    two ranks on one GPU) and prints the report's scalability table."""
+    out = str(tmp_path / "records.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scaling_study.py"), "--gpus", "1",
+                        "2", "--modes", "part2a", "part3", "--transport", "loopback", "--batch-size",
+                        "32", "--steps", "4", "--warmup", "2", "--windows", "1", "--json", out],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("part")]
+    assert [(x[0], x[1]) for x in rows] == [("part2a", "1"), ("part2a", "2"), ("part3", "1"), ("part3", "2")]
+    assert rows[0][4] == "100.0%" and rows[2][4] == "100.0%"
+    recs = json.load(open(out))
+    assert len(recs) == 4 and recs[1]["params_in_sync"] is True and recs[3]["params_in_sync"] is True
+    assert recs[3]["config"]["overlap"] is not None
