@@ -106,7 +106,12 @@ BucketReducer::~BucketReducer() {
 void BucketReducer::begin_step() {
     launched_.assign(slices_.size(), 0);
     last_ready_ = -1;
-    ++step_seq_;
+    if (++step_seq_ == 0 && ready_flags_) {
+        // the 32-bit sequence wrapped (2^32 steps): start the flag words over
+        check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(sequence wrap)");
+        check_hip(hipMemset(ready_flags_, 0, 2 * slices_.size() * sizeof(unsigned)), "hipMemset(bucket flags)");
+        step_seq_ = 1;
+    }
 }
 
 void BucketReducer::bucket_ready(int b, hipStream_t compute,

@@ -606,7 +606,12 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
     side_done_by_value_ = false;
     // (a captured graph keeps the event pair: its edges come from the capture)
     const bool by_value = side && value_hand_off_ && !capturing_;
-    if (by_value) ++backward_seq_;
+    if (by_value && ++backward_seq_ == 0) {
+        // the 32-bit sequence wrapped (2^32 backward passes): start the words over
+        check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(sequence wrap)");
+        check_hip(hipMemset(hand_off_flags_, 0, (convs_.size() + 1) * sizeof(unsigned)), "hipMemset(hand-off flags)");
+        backward_seq_ = 1;
+    }
     const bool fuse_opt = side && opt_.on;
     opt_applied_ = fuse_opt;
     int updated_above = nconv + 1;      // layers >= this already had their parameters updated

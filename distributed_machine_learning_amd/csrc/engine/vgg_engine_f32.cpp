@@ -353,7 +353,13 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
     sums_.n = 0;
     float* tb = arena_ + tb_off_;
     const bool by_value = overlap_ && value_hand_off_;
-    if (by_value) ++backward_seq_;
+    if (by_value && ++backward_seq_ == 0) {
+        // the 32-bit sequence wrapped (2^32 backward passes): start the words over
+        check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(sequence wrap)");
+        check_hip(hipMemset(hand_off_flags_, 0, (lay_.convs.size() + 3) * sizeof(unsigned)), "hipMemset(hand-off flags)");
+        backward_seq_ = 1;
+        join_seq_[0] = join_seq_[1] = join_seq_[2] = 0;
+    }
 
     const ParamLayout::Conv& last = lay_.convs[nconv - 1];
     const float* fc_in = arena_ + (last.pool_after ? buf_[nconv - 1].pool_off : buf_[nconv - 1].out_off);
