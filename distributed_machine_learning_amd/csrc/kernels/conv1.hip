@@ -14,6 +14,8 @@
 //
 // Backward-weight trick: im2col column k = 36 is set to 1.0, so the same MFMA that
 // produces dW[co][k] yields the bias gradient sum_p dy[p][co] in column 36 for free.
+#include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 
 #include "dml_common.h"
@@ -27,9 +29,22 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4_c1;
 
 }  // namespace
 
+// Output channel held in accumulator element c of MFMA tile i by lane group lq (rows 4*lq ..
+// 4*lq+3 of every 16-row tile).  Tiles 0/1 give a lane the eight consecutive channels 8*lq ..
+// 8*lq+7 and tiles 2/3 the eight channels 32 + 8*lq ..: each of the two 16-byte stores of a
+// pixel then lands next to its neighbours' - the four lane groups write one contiguous 64-byte
+// half of the pixel's 128-byte row per store instruction.
+// (HALVES = false: the earlier order, 16 consecutive channels per lane group, whose two stores
+// interleave 16-byte pieces of the row; kept for comparison, DML_CONV1_STORE=interleaved)
+template <bool HALVES>
+__device__ __forceinline__ int conv1_out_channel(int i, int lq, int c) {
+    return HALVES ? (i >> 1) * 32 + lq * 8 + (i & 1) * 4 + c : lq * 16 + i * 4 + c;
+}
+
 // ------------------------------------------------------------------------- forward
 // Block: 256 pixels x 64 output channels, K = 64 in one step.  Wave w owns pixels
 // [64w, 64w+64).  Accumulator layout D[co][pixel] as in the generic kernel.
+template <bool HALVES>
 __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __restrict__ x,
                                                           const uint16_t* __restrict__ w1,
                                                           const float* __restrict__ bias,
@@ -67,11 +82,8 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
     for (int i = 0; i < 2; ++i) {
         const int chunk = tid + 256 * i;
         const int r = chunk >> 3, c = chunk & 7;
-        // Output-channel order of the four 16-row MFMA tiles: row q of tile i holds channel
-        // 16*(q>>2) + 4*i + (q&3), so that a lane's accumulators (rows 4*lq .. 4*lq+3 of every
-        // tile) are the 16 CONSECUTIVE channels 16*lq .. 16*lq+15 of its pixel: the result
-        // leaves as two 16-byte stores per pixel and four lanes complete a 128-byte row.
-        const int ch = 16 * ((r & 15) >> 2) + 4 * (r >> 4) + (r & 3);
+        // output-channel order of the four 16-row MFMA tiles: see conv1_out_channel
+        const int ch = conv1_out_channel<HALVES>(r >> 4, (r & 15) >> 2, r & 3);
         *(uint4*)(sB + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = *(const uint4*)(w1 + ch * 64 + c * 8);
     }
     __syncthreads();
@@ -122,8 +134,8 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    red[(wave * 2 + 0) * 64 + lq * 16 + i * 4 + c] = s1[i][c];
-                    red[(wave * 2 + 1) * 64 + lq * 16 + i * 4 + c] = s2[i][c];
+                    red[(wave * 2 + 0) * 64 + conv1_out_channel<HALVES>(i, lq, c)] = s1[i][c];
+                    red[(wave * 2 + 1) * 64 + conv1_out_channel<HALVES>(i, lq, c)] = s2[i][c];
                 }
         }
         __syncthreads();
@@ -136,8 +148,8 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
     }
     float bv[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 b = *(const float4*)(bias + lq * 16 + q * 4);
+    for (int q = 0; q < 4; ++q) {       // (tile q's four channels are consecutive)
+        const float4 b = *(const float4*)(bias + conv1_out_channel<HALVES>(q, lq, 0));
         bv[q * 4 + 0] = b.x; bv[q * 4 + 1] = b.y; bv[q * 4 + 2] = b.z; bv[q * 4 + 3] = b.w;
     }
 #pragma unroll
@@ -155,9 +167,9 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const uint16_t* __rest
             o[2 * i] = pack2(v0, v1);
             o[2 * i + 1] = pack2(v2, v3);
         }
-        uint16_t* dst = y + (size_t)m * 64 + lq * 16;
-        *(uint4*)dst = make_uint4(o[0], o[1], o[2], o[3]);
-        *(uint4*)(dst + 8) = make_uint4(o[4], o[5], o[6], o[7]);
+        uint16_t* dst = y + (size_t)m * 64 + (HALVES ? lq * 8 : lq * 16);
+        *(uint4*)dst = make_uint4(o[0], o[1], o[2], o[3]);           // channels 8*lq ..
+        *(uint4*)(dst + (HALVES ? 32 : 8)) = make_uint4(o[4], o[5], o[6], o[7]);    // 32 + 8*lq ..
     }
 }
 
@@ -169,8 +181,14 @@ void conv1_fprop(const bf16_raw* x, const bf16_raw* w1, const float* bias, bf16_
     if ((long long)batch * 1024 * 128 >= (1LL << 31))
         throw std::invalid_argument("conv1_fprop: batch too large");
     const int M = batch * 1024;
-    hipLaunchKernelGGL(conv1_fprop_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, x, w1, bias,
-                       y, M, relu ? 1 : 0, stats);
+    static const bool halves = !(getenv("DML_CONV1_STORE") &&
+                                 !strcmp(getenv("DML_CONV1_STORE"), "interleaved"));
+    if (halves)
+        hipLaunchKernelGGL(conv1_fprop_kernel<true>, dim3((M + 255) / 256), dim3(256), 0, stream, x,
+                           w1, bias, y, M, relu ? 1 : 0, stats);
+    else
+        hipLaunchKernelGGL(conv1_fprop_kernel<false>, dim3((M + 255) / 256), dim3(256), 0, stream, x,
+                           w1, bias, y, M, relu ? 1 : 0, stats);
 }
 
 // ------------------------------------------------------------------ backward-weight
