@@ -213,6 +213,7 @@ class VggEngine {
     bool tuned_wgrad_splits_ = true;        // use conv3x3_wgrad_tuned_splits where it has an entry
     // tuning (DML_DGRAD_PLANS): backward-data plan {bm, bn, splits, pm, waves} per conv layer, bm 0 = default
     std::vector<std::array<int, 5>> dgrad_force_plan_;
+    int dgrad_plan_batch_ = 0;              // > 0: the plans above are tuned defaults for this batch size only
     std::vector<int> wgrad_force_splits_;   // tuning (DML_WGRAD_SPLITS): pixel splits per conv layer, 0 = planned
     // tuning (DML_WGRAD_RESIDENT): "bco:stages" per conv layer to run the tap-resident kernel there
     // (with the layer's DML_WGRAD_SPLITS entry as its split count), "0" for the per-tap kernel
