@@ -368,7 +368,7 @@ int conv3x3_wgrad_tuned_splits(ConvShape s, bool batch_norm) {
     if (s.batch != 256) return 0;
     struct Entry { int hw, cin, cout, bn, plain; };
     static const Entry table[] = {
-        {16, 64, 128, 40, 36}, {8, 128, 256, 10, 12}, {8, 256, 256, 10, 12},
+        {16, 64, 128, 40, 36}, {8, 128, 256, 10, 15}, {8, 256, 256, 10, 12},
         {4, 256, 512, 2, 6},   {4, 512, 512, 3, 2},   {2, 512, 512, 1, 1},
     };
     for (const Entry& e : table)
