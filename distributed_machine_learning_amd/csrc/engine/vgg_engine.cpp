@@ -238,7 +238,8 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
             if (*q == ',') ++q;
         }
     }
-    else if (bn_ && max_batch_ == 256) {
+    if (const char* e = getenv("DML_FUSED_FINISH_BN")) fused_finish_bn_ = atoi(e) != 0;
+    if (!getenv("DML_DGRAD_PLANS") && bn_ && max_batch_ == 256) {
         // Tuned inside the step (tools/tune_dgrad_plans.py, tools/ab_dgrad_l4.sh): the backward-data
         // pass of a 256 -> 512 layer on 4x4 maps runs 2.5 us per step faster on the 64 x 64
         // patch-resident kernel than on the default tap-split plan - a block that owns its pixel
@@ -550,7 +551,27 @@ void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t
         // in training the conv epilogue also leaves the BatchNorm statistics partials
         BnPartials part;
         float* cstats = (bn_ && training) ? ws_ + cstats_off_ : nullptr;
-        if (i == 0) {
+        if (i > 0 && cstats && c.hw == 2 && fused_finish_bn_ && batch <= 256 && c.cout % 16 == 0) {
+            // 2x2 maps: the tap-split convolution leaves its slabs, and one launch sums them,
+            // takes the statistics and applies BatchNorm + ReLU (+ pool), see splitk_finish_bn_relu
+            ConvShape s = {batch, c.hw, c.cin, c.cout};
+            SplitSlabs pend;
+            conv3x3_igemm(in, arena_ + shadow_off_ + c.w_off, dst, nullptr, nullptr, slab, slab_elems_,
+                          s, EPI_NONE, stream, nullptr, nullptr, &pend);
+            uint16_t* act = arena_ + (c.pool_after ? c.pool_off : c.out_off);
+            if (pend.splits > 1 &&
+                splitk_finish_bn_relu(pend, params_ + c.b_off, dst, act, params_ + c.gamma_off,
+                                      params_ + c.beta_off, bnbuf_ + c.rm_off, bnbuf_ + c.rv_off,
+                                      ws_ + c.save_off, ws_ + c.save_off + c.cout, batch, c.hw, c.cout,
+                                      c.pool_after, 0.1f, 1e-5f, stream)) {
+                in = act;
+                continue;
+            }
+            // (an un-split plan, or a shape the fused kernel does not cover: the usual path)
+            conv3x3_igemm(in, arena_ + shadow_off_ + c.w_off, dst, params_ + c.b_off, nullptr, slab,
+                          slab_elems_, s, EPI_BIAS, stream, nullptr, cstats);
+            part.rows = conv3x3_igemm_stats_rows(s);
+        } else if (i == 0) {
             conv1_fprop(in, arena_ + w1_off_, params_ + c.b_off, dst, batch, !bn_, stream, cstats);
             part.rows = conv1_fprop_stats_rows(batch);
         } else {

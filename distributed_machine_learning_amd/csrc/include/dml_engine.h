@@ -213,6 +213,9 @@ class VggEngine {
     bool tuned_wgrad_splits_ = true;        // use conv3x3_wgrad_tuned_splits where it has an entry
     // tuning (DML_DGRAD_PLANS): backward-data plan {bm, bn, splits, pm, waves} per conv layer, bm 0 = default
     std::vector<std::array<int, 5>> dgrad_force_plan_;
+    // forward of the 2x2 layers under BatchNorm: split-K finish + statistics + apply in one launch
+    // (DML_FUSED_FINISH_BN=1; measured equal to the two launches it replaces, so off by default)
+    bool fused_finish_bn_ = false;
     int dgrad_plan_batch_ = 0;              // > 0: the plans above are tuned defaults for this batch size only
     std::vector<int> wgrad_force_splits_;   // tuning (DML_WGRAD_SPLITS): pixel splits per conv layer, 0 = planned
     // tuning (DML_WGRAD_RESIDENT): "bco:stages" per conv layer to run the tap-resident kernel there

@@ -238,6 +238,14 @@ bool bn_bwd_single_launch(int dy_rows, int c);
 // [batch][hw][hw][c], y / dy the pooled tensor [batch][hw/2][hw/2][c]).  The full-resolution
 // activation and its gradient are never materialised: backward recomputes the winning
 // window position from x.
+// Split-K finish, batch statistics, BatchNorm + ReLU (+ 2x2 max-pool) of a layer on 2x2 maps in one
+// launch (a block owns 16 channels and all 4 * batch rows).  `slabs`: the convolution's unsummed
+// bias-free fp32 slabs; writes the bf16 conv output `pre` (bias added) and the activation `out`
+// ([4 * batch][c], or [batch][c] pooled).  false: shape outside the kernel's range, nothing launched.
+bool splitk_finish_bn_relu(const SplitSlabs& slabs, const float* bias, bf16_raw* pre, bf16_raw* out,
+                           const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* save_mean, float* save_rstd, int batch, int hw,
+                           int c, bool pool, float momentum, float eps, hipStream_t stream);
 void bn_relu_pool_fwd_train(const bf16_raw* x, bf16_raw* y, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float* save_mean,
                             float* save_rstd, float* ws, int batch, int hw, int c, float momentum,

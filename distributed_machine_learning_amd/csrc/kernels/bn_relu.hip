@@ -11,6 +11,8 @@
 // and finalises (mean / rstd / running statistics forward, dgamma / dbeta backward) - no
 // memset, no result atomics.  The apply kernels then stream the tensor once with
 // per-channel constants held in registers.  All statistics stay fp32.
+#include <cstdlib>
+#include <type_traits>
 #include <stdexcept>
 #include <string>
 
@@ -1145,6 +1147,195 @@ void bn_relu_pool_bwd(const float* x, float* dy, float* dx, const float* gamma, 
     hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<float>, dim3(apply_blocks(total8)), dim3(256), 0,
                        stream, x, (const float*)dy, dx, gamma, beta, save_mean, save_rstd,
                        (const float*)dgamma, (const float*)dbeta, rows, c, geo, total8);
+}
+
+// ------------------------------------------------ split-K finish + BatchNorm + ReLU (+ pool), 2x2 maps
+// The two deepest VGG layers run on 2x2 maps: 4 * batch rows, so their convolutions split the taps
+// and leave fp32 slabs.  Summing the slabs, the batch statistics and the normalisation then are
+// three dependent launches of ~6 us for a few MB.  Here one block owns 16 channels and ALL rows
+// (16 rows x 4 channels per thread, in registers), so the statistics are complete inside the block
+// and everything happens in one launch: slab sum (+ bias) -> bf16 conv output for backward,
+// bias-free column sums -> mean / rstd / running statistics, scale / shift / ReLU (and the 2x2
+// max-pool: a window is 4 consecutive rows, all in one thread) -> bf16 activation.
+// The activation is formed from the bf16-rounded conv output, like the separate apply pass does.
+// CPB channels per block: 16 (32 blocks at 512 channels) or 8 (64 blocks, half the rows per thread;
+// a row piece is then 32 bytes per slab, but the slabs sit in L2 and the launch is bound by its
+// dependent round trips, not by bytes)
+template <bool POOL, int CPB>
+__global__ __launch_bounds__(256) void splitk_finish_bn_kernel(
+    const float* __restrict__ slabs, int splits, size_t slab_stride, const float* __restrict__ bias,
+    uint16_t* __restrict__ pre, uint16_t* __restrict__ out, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float* __restrict__ save_mean, float* __restrict__ save_rstd, int batch, int c, float momentum,
+    float eps) {
+    constexpr int QB = CPB / 4;             // channel quads per block
+    constexpr int RL = 256 / QB;            // row lanes (one image = one 4-row window each)
+    constexpr int W = 256 / RL;             // windows per thread at batch 256
+    constexpr int COLS = 2 * CPB;           // statistics columns: sums, sums of squares
+    __shared__ float part[RL][COLS + 1];
+    __shared__ float part2[8][COLS];
+    __shared__ float stat[2][CPB];          // mean, rstd
+    const int tid = threadIdx.x, q = tid % QB, rl = tid / QB;
+    const int col = blockIdx.x * CPB + q * 4;
+    const int rows = batch * 4;
+    const float4 b4 = *(const float4*)(bias + col);
+    float v[W][4][4];                       // [window][row of the window][channel], bias-free sums
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[w][j][k] = 0.f;
+    // All loads of a thread in flight together: the launch is bound by its dependent round trips
+    // to L2, not by bytes.  (With the run-time loop over the splits INSIDE the row loops every row
+    // became a chain of round trips: 16 us per launch; split by split: 3 round trips; with the
+    // usual three splits unrolled, where the registers allow it: one.)
+    auto load_splits = [&](auto nsplit_tag) {
+        constexpr int NS = decltype(nsplit_tag)::value;
+        float4 t[NS][W][4];
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx)
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const int img = w * RL + rl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    t[sidx][w][j] = img < batch
+                        ? *(const float4*)(slabs + sidx * slab_stride + col + (size_t)(img * 4 + j) * c)
+                        : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx)       // (fixed order: split 0 first)
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[w][j][0] += t[sidx][w][j].x; v[w][j][1] += t[sidx][w][j].y;
+                    v[w][j][2] += t[sidx][w][j].z; v[w][j][3] += t[sidx][w][j].w;
+                }
+    };
+    if (splits == 3 && W <= 2) {
+        load_splits(std::integral_constant<int, 3>{});
+    } else {
+        for (int sidx = 0; sidx < splits; ++sidx) {
+            const float* sl = slabs + sidx * slab_stride + col;
+            float4 t[W][4];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const int img = w * RL + rl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    t[w][j] = img < batch ? *(const float4*)(sl + (size_t)(img * 4 + j) * c)
+                                          : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[w][j][0] += t[w][j].x; v[w][j][1] += t[w][j].y;
+                    v[w][j][2] += t[w][j].z; v[w][j][3] += t[w][j].w;
+                }
+        }
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s1[k] += v[w][j][k];
+                s2[k] += v[w][j][k] * v[w][j][k];
+            }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        part[rl][q * 4 + k] = s1[k];
+        part[rl][CPB + q * 4 + k] = s2[k];
+    }
+    __syncthreads();
+    if (tid < 8 * COLS) {                   // eight row segments per column, then the eight sums
+        const int cidx = tid % COLS, seg = tid / COLS;
+        float acc = 0.f;
+        for (int r = seg * (RL / 8); r < (seg + 1) * (RL / 8); ++r) acc += part[r][cidx];
+        part2[seg][cidx] = acc;
+    }
+    __syncthreads();
+    if (tid < CPB) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int seg = 0; seg < 8; ++seg) {
+            t1 += part2[seg][tid];
+            t2 += part2[seg][CPB + tid];
+        }
+        const int ch = blockIdx.x * CPB + tid;
+        const float inv_n = 1.f / (float)rows;
+        const float m0 = t1 * inv_n;
+        const float var = fmaxf(t2 * inv_n - m0 * m0, 0.f);
+        const float mean = m0 + bias[ch];           // the sums are bias-free: a shift moves the mean only
+        const float rs = rsqrtf(var + eps);
+        stat[0][tid] = mean;
+        stat[1][tid] = rs;
+        save_mean[ch] = mean;
+        save_rstd[ch] = rs;
+        if (running_mean) {
+            const float unbiased = rows > 1 ? var * ((float)rows / (float)(rows - 1)) : var;
+            running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean;
+            running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+        }
+    }
+    __syncthreads();
+    float sc[4], sh[4];
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sc[k] = gamma[col + k] * stat[1][q * 4 + k];
+        sh[k] = beta[col + k] - stat[0][q * 4 + k] * sc[k];
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int img = w * RL + rl;
+        if (img >= batch) continue;
+        float best[4] = {0.f, 0.f, 0.f, 0.f};       // ReLU = max with 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint16_t pb[4];
+            float z[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pb[k] = float_to_bf16_bits(v[w][j][k] + bb[k]);
+                z[k] = fmaxf(__builtin_fmaf(bf16_bits_to_float(pb[k]), sc[k], sh[k]), 0.f);
+                best[k] = fmaxf(best[k], z[k]);
+            }
+            const size_t at = (size_t)(img * 4 + j) * c + col;
+            *(uint2*)(pre + at) = make_uint2((uint32_t)pb[0] | ((uint32_t)pb[1] << 16),
+                                             (uint32_t)pb[2] | ((uint32_t)pb[3] << 16));
+            if (!POOL) *(uint2*)(out + at) = make_uint2(pack2(z[0], z[1]), pack2(z[2], z[3]));
+        }
+        if (POOL)
+            *(uint2*)(out + (size_t)img * c + col) =
+                make_uint2(pack2(best[0], best[1]), pack2(best[2], best[3]));
+    }
+}
+
+bool splitk_finish_bn_relu(const SplitSlabs& slabs, const float* bias, bf16_raw* pre, bf16_raw* out,
+                           const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* save_mean, float* save_rstd, int batch, int hw,
+                           int c, bool pool, float momentum, float eps, hipStream_t stream) {
+    if (slabs.splits < 1 || !slabs.data || hw != 2 || c % 16 || batch < 1 || batch > 256 ||
+        slabs.stride % 4)
+        return false;
+    static const int cpb = getenv("DML_FINISH_BN_CPB") ? atoi(getenv("DML_FINISH_BN_CPB")) : 16;
+#define DML_LAUNCH_FINISH_BN(POOL, CPB)                                                              \
+    hipLaunchKernelGGL((splitk_finish_bn_kernel<POOL, CPB>), dim3(c / CPB), dim3(256), 0, stream,    \
+                       slabs.data, slabs.splits, slabs.stride, bias, pre, out, gamma, beta,          \
+                       running_mean, running_var, save_mean, save_rstd, batch, c, momentum, eps)
+    if (cpb == 16) {
+        if (pool) DML_LAUNCH_FINISH_BN(true, 16); else DML_LAUNCH_FINISH_BN(false, 16);
+    } else {
+        if (pool) DML_LAUNCH_FINISH_BN(true, 8); else DML_LAUNCH_FINISH_BN(false, 8);
+    }
+#undef DML_LAUNCH_FINISH_BN
+    return true;
 }
 
 }  // namespace dml

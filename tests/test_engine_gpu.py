@@ -383,6 +383,31 @@ def test_wgrad_side_stream_matches_single_stream(batch_norm, mode):
             comm.destroy()
 
 
+@pytest.mark.parametrize("cpb", ["8", "16"])
+def test_fused_split_finish_batchnorm_matches_separate_launches(cpb, monkeypatch):
+    """Opt-in forward of the 2x2 layers (DML_FUSED_FINISH_BN=1): split-K finish, batch statistics
+    and BatchNorm + ReLU (+ pool) in one launch.  Same arithmetic as the separate launches up to
+    the order of the fp32 sums."""
+    base, _ = _mk(True, batch=64)
+    monkeypatch.setenv("DML_FUSED_FINISH_BN", "1")
+    monkeypatch.setenv("DML_FINISH_BN_CPB", cpb)
+    fused, _ = _mk(True, batch=64)
+    monkeypatch.delenv("DML_FUSED_FINISH_BN")
+    for step in range(3):
+        _, x4, t = _batch(64, seed=step)
+        la = float(base.train_step(x4, t))
+        lb = float(fused.train_step(x4, t))
+        # the first step differs by rounding only; later ones also by what those roundings did
+        # to the bf16 activations of the steps before
+        tol = 2e-4 if step == 0 else 1e-2
+        assert abs(la - lb) <= tol * max(1.0, abs(la)), (step, la, lb)
+    torch.cuda.synchronize()
+    assert _rel(fused.params, base.params) < 1e-2
+    assert _rel(fused.bn_buffers, base.bn_buffers) < 1e-2
+    base.close()
+    fused.close()
+
+
 @pytest.mark.parametrize("batch_norm", [False, True])
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_flag_word_hand_offs_match_event_hand_offs(batch_norm, dtype, monkeypatch):
