@@ -239,7 +239,11 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         }
     }
     if (const char* e = getenv("DML_FUSED_FINISH_BN")) fused_finish_bn_ = atoi(e) != 0;
-    if (!getenv("DML_DGRAD_PLANS") && bn_ && max_batch_ == 256) {
+    const char* tall_env = getenv("DML_TALL_TILES");
+    const bool tall_tiles = !(tall_env && tall_env[0] == '0');
+    // (with the tall patch-resident tiles every backward-data pass of the flagship shapes owns its
+    // pixel tiles already; the override below belongs to the older plans)
+    if (!getenv("DML_DGRAD_PLANS") && bn_ && max_batch_ == 256 && !tall_tiles) {
         // Tuned inside the step (tools/tune_dgrad_plans.py, tools/ab_dgrad_l4.sh): the backward-data
         // pass of a 256 -> 512 layer on 4x4 maps runs 2.5 us per step faster on the 64 x 64
         // patch-resident kernel than on the default tap-split plan - a block that owns its pixel

@@ -1,0 +1,415 @@
+// conv3x3 (stride 1, pad 1) forward and backward-data: patch-resident MFMA implicit GEMM with
+// tall pixel tiles.
+//
+// Reference op: nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, bias=True)
+// (/root/reference/part1/model.py:18-23) and its autograd input gradient
+// (loss.backward(), /root/reference/part1/main.py:44).
+//
+// Why this form.  A CU takes in about 29 bytes per clock from L2 into LDS (LDS-DMA, measured), and
+// its matrix cores finish a 64-deep K step of a 128 x 128 tile in 512 clocks.  The streaming kernel
+// of conv_igemm.hip fetches (128 + 128) rows x 128 bytes for that step - 1130 clocks of feed - so it
+// runs at the feed rate, not at the matrix rate.  Two things cut the bytes per flop:
+//   * the pixels a tile touches are fetched ONCE per 64-channel chunk (the tile's BM pixels plus
+//     hw + 1 pixels of halo on either side) and the nine taps read that one LDS copy at nine row
+//     shifts (in NHWC the (dh, dw) neighbour of pixel m is pixel m + dh*hw + dw);
+//   * the weights, which then dominate, are amortised over a TALL tile: BM = 256 pixels x BN = 64
+//     channels has the area of 128 x 128 but fetches (BM + 2*hw + 2 + 9*BN) rows per chunk instead
+//     of 9 * 256, i.e. 12 KB instead of 32 KB per K step - under the matrix time.
+//
+// LDS image.  Rows are 128 bytes (64 channels); the 16-byte group c of row r sits in slot
+//   slot(r, c) = 4 * (c & 1) + ((c >> 1) ^ ((r >> 1) & 3)).
+// A ds_read_b128 is served in groups of 16 lanes that hold rows a .. a+3, a+12 .. a+15 of one K
+// group and rows a+4 .. a+11 of the next one (c differs in bit 0): the two sets land in different
+// 64-byte halves, and each set covers every row residue mod 8 once, so (row & 1, slot) is a
+// bijection onto the 16 slots of the 256-byte bank row for EVERY start row a - the nine shifted
+// reads are conflict-free, not only the aligned one.  The global -> LDS copies are lane-linear
+// (LDS-DMA), so the permutation is applied on the source side: lane (row, slot) fetches the group
+// that belongs in its slot.
+//
+// Padding without touching the data: every patch buffer starts with two zero rows, and a lane
+// whose (pixel, tap) falls outside the image reads the zero row of its row's parity at its own
+// slot (same banks as the real read).  The 9 per-tap addresses of a lane's TM pixels are computed
+// once; a K step costs no address arithmetic beyond one XOR per fragment for the second K half.
+//
+// Pipeline.  Weights stream through a 3-stage ring, one stage = one filter row (3 taps x BN rows),
+// two stages in flight; the patch of chunk c+1 is requested during the first stage of chunk c into
+// the other patch buffer.  One raw s_barrier per stage (1536 matrix clocks at 256 x 64), counted
+// vmcnt waits - every count is a compile-time constant because a chunk (9 taps = 3 stages) is
+// unrolled; fragments are double-buffered in registers and the first fragments of a stage are
+// requested right after its barrier, under the MFMAs of the previous stage's last half step.
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+
+#include "dml_conv_tile.h"
+
+namespace dml {
+namespace igemm {
+
+namespace {
+
+__device__ __forceinline__ int slot_of(int r, int c) {
+    return ((c & 1) << 2) | ((c >> 1) ^ ((r >> 1) & 3));
+}
+__device__ __forceinline__ int group_in_slot(int r, int s) {
+    return (((s & 3) ^ ((r >> 1) & 3)) << 1) | (s >> 2);
+}
+
+template <int V> using ic = std::integral_constant<int, V>;
+
+constexpr int kTapsPerStage = 3, kStages = 3;
+
+template <int BM, int NW>
+struct PatchGeom {
+    static constexpr int kMaxRows = BM + 2 * 17;                  // hw <= 16
+    static constexpr int kGroups = (kMaxRows + 7) / 8;
+    static constexpr int kIters = (kGroups + NW - 1) / NW;        // wave-loads per chunk and wave
+    static constexpr int kBytes = 256 + kIters * NW * 1024;       // two zero rows + the rows
+};
+
+}  // namespace
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(IgemmArgs p) {
+    raise_stream_signal(p);
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int TPS = kTapsPerStage, WS = kStages;
+    constexpr int WSTAGE = TPS * BN * 128;
+    constexpr int W_IT = TPS * BN / 8 / NW;             // weight wave-loads per stage and wave
+    static_assert((TPS * BN / 8) % NW == 0, "stage must divide over the waves");
+    static_assert(TM >= 1 && TN >= 1, "tile too small for this many waves");
+    using PG = PatchGeom<BM, NW>;
+    constexpr int P_IT = PG::kIters, PBUF = PG::kBytes;
+    constexpr int RING = WS * WSTAGE;
+
+    extern __shared__ __attribute__((aligned(256))) char smem[];      // [ring][patch 0][patch 1]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    int bid = blockIdx.x;       // XCD-contiguous tile ranges (blocks are dealt round-robin to 8 XCDs)
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int C = p.C, hw = p.hw;
+    const int chunks = 1 << p.log_chunks;
+    const int halo = hw + 1;
+
+    // the zero rows of both patch buffers
+    if (tid < 32) {
+        *(uint4*)(smem + RING + (tid >> 4) * PBUF + (tid & 15) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    // ---- global -> LDS: per lane a fixed byte offset, everything that changes with the tap row
+    // and the channel chunk is wave-uniform and travels in the scalar offset
+    const int lrow = lane >> 3, slot = lane & 7;
+    int w_off[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int q = i * NW + wave;                     // 1 KiB piece of the stage
+        const int tap_in_stage = q / (BN / 8), r = (q % (BN / 8)) * 8 + lrow;
+        w_off[i] = ((n0 + permuted_channel<WTN>(r)) * 9 * C + tap_in_stage * C +
+                    group_in_slot(r, slot) * 8) * 2;
+    }
+    int p_off[P_IT];
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+        const int prow = (wave + NW * i) * 8 + lrow;
+        const int pix = m0 - halo + prow;
+        const bool ok = prow < BM + 2 * halo && pix >= 0 && pix < p.M;
+        p_off[i] = ok ? (pix * C + group_in_slot(prow, slot) * 8) * 2 : kOutOfRange;
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    auto issue_patch = [&](int cc) {
+        char* dst = smem + RING + (cc & 1) * PBUF + 256 + wave * 1024;
+        const int soff = cc * 128;
+#pragma unroll
+        for (int i = 0; i < P_IT; ++i) {
+            const int voff = p_off[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(dst + i * NW * 1024), 16, voff,
+                                                     soff, 0, 0);
+        }
+    };
+    auto issue_w = [&](int cc, int row /* filter row = stage */) {
+        char* dst = smem + row * WSTAGE + wave * 1024;
+        const int soff = (3 * row * C + cc * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+            const int voff = w_off[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(dst + i * NW * 1024), 16, voff,
+                                                     soff, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses (bytes from smem), K half 0; the second half is ^ 32
+    const int l15 = lane & 15, lq = lane >> 4;
+    int wa[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int r = wn * WTN + i * 16 + l15;
+        wa[i] = r * 128 + slot_of(r, lq) * 16;
+    }
+    int pa[TM][9];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int rt = wm * WTM + j * 16 + l15;
+        const int m = m0 + rt;
+        const int w_ = m & (hw - 1), h_ = (m >> p.log_hw) & (hw - 1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dh = t / 3 - 1, dw = t % 3 - 1;
+            const bool valid = m < p.M && (unsigned)(h_ + dh) < (unsigned)hw &&
+                               (unsigned)(w_ + dw) < (unsigned)hw;
+            const int pr = rt + halo + dh * hw + dw;
+            const int in_row = slot_of(pr, lq) * 16;
+            pa[j][t] = RING + (valid ? 256 + pr * 128 : (pr & 1) * 128) + in_row;
+        }
+    }
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // sub-step u of a chunk: tap u / 2, K half u & 1; PAR = patch buffer of the chunk
+    auto load_frags = [&](auto par_c, auto u_c, bf16x8 (&wf)[TN], bf16x8 (&xf)[TM]) {
+        constexpr int PAR = decltype(par_c)::value, U = decltype(u_c)::value;
+        constexpr int T = U / 2, KX = (U & 1) * 32;
+        constexpr int woff = (T / TPS) * WSTAGE + (T % TPS) * BN * 128;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8*)(smem + ((wa[i] ^ KX) + woff));
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8*)(smem + ((pa[j][T] ^ KX) + PAR * PBUF));
+    };
+    auto mma = [&](const bf16x8 (&wf)[TN], const bf16x8 (&xf)[TM]) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    };
+
+    // Issue order of a sub-step, pinned for the compiler's scheduler (left alone it sinks every
+    // fragment read down to its first use and the register double buffer is gone): the reads of
+    // the NEXT sub-step alternate with the MFMAs of this one.
+    auto interleave = [&]() {
+#pragma unroll
+        for (int k = 0; k < TN + TM; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (TN * TM) / (TN + TM), 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TN * TM - (TN + TM) * ((TN * TM) / (TN + TM)), 0);
+    };
+
+    // (un-pooled BatchNorm backward sums in the epilogue want the layer's conv output values of
+    // this tile: requested during the last chunk, see bn_plain_bwd_prefetch)
+    constexpr bool kBnBwd = EPI == EPI_NONE;
+    uint32_t bn_xv[kBnBwd ? TM : 1][2 * TN];
+    const bool bn_plain = kBnBwd && p.bn_pre != nullptr && !p.bn_pooled;
+
+    auto bn_prefetch = [&]() {
+        if constexpr (kBnBwd)
+            bn_plain_bwd_prefetch<TN, TM>(p, m0 + wm * WTM + l15, n0 + wn * WTN + lq * 4 * TN, bn_xv);
+    };
+
+    bf16x8 wfa[TN], xfa[TM], wfb[TN], xfb[TM];
+
+    // One chunk = 3 stages = 18 sub-steps.  On entry the fragments of sub-step 0 are in (wfa, xfa)
+    // and the barrier of the chunk's first stage has been passed.  Loads issued after the barrier
+    // of stage (cc, i): the weights two stages ahead (filter row (i + 2) % 3 of this or the next
+    // chunk) and, in the first stage, the next chunk's patch; the wait in front of the NEXT
+    // barrier lets exactly those stay in flight.
+    auto chunk = [&](auto par_c, auto last_c, int cc) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool LAST = decltype(last_c)::value != 0;
+        auto after_barrier = [&](auto i_c) {          // loads issued behind the barrier of stage i
+            constexpr int I = decltype(i_c)::value;
+            if constexpr (!LAST) {
+                if constexpr (I == 0) { issue_w(cc, 2); issue_patch(cc + 1); }
+                else issue_w(cc + 1, I - 1);
+            } else {
+                if constexpr (I == 0) issue_w(cc, 2);
+                if constexpr (I == 1)
+                    if (bn_plain) bn_prefetch();
+            }
+        };
+        auto wait_for_next = [&](auto i_c) {          // before the barrier of the stage after (cc, i)
+            constexpr int I = decltype(i_c)::value;
+            if constexpr (!LAST) {
+                if constexpr (I < 2) wait_vmcnt<W_IT + P_IT>();
+                else wait_vmcnt<W_IT>();
+            } else {
+                if constexpr (I == 0) wait_vmcnt<W_IT>();
+                else wait_vmcnt<0>();
+            }
+        };
+        auto stage = [&](auto i_c) {
+            constexpr int I = decltype(i_c)::value;
+            if constexpr (I == 0) after_barrier(ic<0>{});   // (stages 1, 2: issued at their barrier below)
+            load_frags(ic<PAR>{}, ic<6 * I + 1>{}, wfb, xfb);  mma(wfa, xfa);  interleave();
+            load_frags(ic<PAR>{}, ic<6 * I + 2>{}, wfa, xfa);  mma(wfb, xfb);  interleave();
+            load_frags(ic<PAR>{}, ic<6 * I + 3>{}, wfb, xfb);  mma(wfa, xfa);  interleave();
+            load_frags(ic<PAR>{}, ic<6 * I + 4>{}, wfa, xfa);  mma(wfb, xfb);  interleave();
+            load_frags(ic<PAR>{}, ic<6 * I + 5>{}, wfb, xfb);  mma(wfa, xfa);  interleave();
+            if constexpr (LAST && I == 2) {
+                mma(wfb, xfb);
+            } else {
+                // lgkmcnt(0), vmcnt / expcnt untouched: every LDS read of this wave has returned
+                // before another wave's copies may overwrite the stage / patch it read
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                wait_for_next(ic<I>{});
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (I < 2) {
+                    after_barrier(ic<I + 1>{});
+                    load_frags(ic<PAR>{}, ic<6 * I + 6>{}, wfa, xfa);
+                } else {
+                    // (the next chunk issues its own first-stage loads on entry)
+                    load_frags(ic<PAR ^ 1>{}, ic<0>{}, wfa, xfa);
+                }
+                mma(wfb, xfb);
+                interleave();
+            }
+        };
+        stage(ic<0>{});
+        stage(ic<1>{});
+        stage(ic<2>{});
+    };
+
+    issue_patch(0);
+    issue_w(0, 0);
+    issue_w(0, 1);
+    __builtin_amdgcn_s_waitcnt(0xC07F);        // the zero rows
+    wait_vmcnt<W_IT>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(ic<0>{}, ic<0>{}, wfa, xfa);
+    if (chunks == 1) {
+        chunk(ic<0>{}, ic<1>{}, 0);
+    } else {
+        for (int cc = 0; cc + 2 < chunks; cc += 2) {
+            chunk(ic<0>{}, ic<0>{}, cc);
+            chunk(ic<1>{}, ic<0>{}, cc + 1);
+        }
+        chunk(ic<0>{}, ic<0>{}, chunks - 2);
+        chunk(ic<1>{}, ic<1>{}, chunks - 1);
+    }
+
+    // ---- BatchNorm sums for free, one partial row [2][N] per pixel tile (see conv_igemm.hip)
+    const bool bn_bwd = EPI == EPI_NONE && p.bn_pre != nullptr;
+    if (p.stats && (EPI == EPI_BIAS || bn_bwd)) {
+        float s1[TN][4], s2[TN][4];
+        if (bn_bwd) {
+            if constexpr (EPI == EPI_NONE) {
+                if (p.bn_pooled)
+                    bn_pool_bwd_tile_sums<TN, TM>(acc, p, m0 + wm * WTM + l15,
+                                                  n0 + wn * WTN + lq * 4 * TN, s1, s2);
+                else
+                    bn_plain_bwd_tile_sums<TN, TM>(acc, p, bn_xv, m0 + wm * WTM + l15,
+                                                   n0 + wn * WTN + lq * 4 * TN, s1, s2);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {
+                        const float v = acc[i][j][c];
+                        a += v;
+                        b += v * v;
+                    }
+                    s1[i][c] = row16_sum(a);
+                    s2[i][c] = row16_sum(b);
+                }
+        }
+        __syncthreads();
+        float* red = (float*)smem;             // [WAVES_M][2][BN]
+        if (l15 == 0) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int col = wn * WTN + lq * 4 * TN + 4 * i + c;
+                    red[(wm * 2 + 0) * BN + col] = s1[i][c];
+                    red[(wm * 2 + 1) * BN + col] = s2[i][c];
+                }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * BN; idx += NW * 64) {
+            const int which = idx / BN, col = idx - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < WAVES_M; ++q) t += red[(q * 2 + which) * BN + col];
+            p.stats[((size_t)tile_m * 2 + which) * p.N + n0 + col] = t;
+        }
+    }
+
+    // ---- epilogue: lane holds pixel m and its 4*TN consecutive channels
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * WTM + j * 16 + l15;
+        if (m >= p.M) continue;
+        const int n = n0 + wn * WTN + lq * 4 * TN;
+        f32x4 a[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) a[i] = acc[i][j];
+        store_lane_channels<TN, EPI>(a, p.y, p.bias, p.mask, (size_t)m * p.N + n, n);
+    }
+}
+
+namespace {
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+void launch_pr_one(const IgemmArgs& a, hipStream_t stream) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int lds = kStages * kTapsPerStage * BN * 128 + 2 * PatchGeom<BM, NW>::kBytes;
+    static_assert(lds <= 160 * 1024, "tile does not fit the CU's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_pr_kernel<BM, BN, WAVES_M, WAVES_N, EPI>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const dim3 grid(((a.M + BM - 1) / BM) * a.tiles_n);
+    hipLaunchKernelGGL((conv3x3_pr_kernel<BM, BN, WAVES_M, WAVES_N, EPI>), grid, dim3(NW * 64), lds,
+                       stream, a);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_pr_epi(const IgemmArgs& a, int epi, hipStream_t stream) {
+    switch (epi) {
+        case EPI_NONE: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_NONE>(a, stream); break;
+        case EPI_BIAS: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_BIAS>(a, stream); break;
+        case EPI_BIAS_RELU: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_BIAS_RELU>(a, stream); break;
+        default: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_MASK>(a, stream); break;
+    }
+}
+
+}  // namespace
+
+bool conv3x3_pr_supported(int bm, int bn, int hw, int variant) {
+    if (hw > 16 || hw < 2 || bn != 64) return false;
+    if (bm == 256) return variant == 0 || variant == 1;
+    if (bm == 128) return variant == 0;
+    return false;
+}
+
+void launch_pr(const IgemmArgs& a, int bm, int bn, int variant, int epi, hipStream_t stream) {
+    if (!conv3x3_pr_supported(bm, bn, a.hw, variant))
+        throw std::invalid_argument("conv3x3_igemm: unsupported patch-resident tile");
+    if (bm == 256 && variant == 0) launch_pr_epi<256, 64, 8, 1>(a, epi, stream);
+    else if (bm == 256) launch_pr_epi<256, 64, 4, 1>(a, epi, stream);
+    else launch_pr_epi<128, 64, 4, 1>(a, epi, stream);
+}
+
+}  // namespace igemm
+}  // namespace dml

@@ -120,6 +120,43 @@ def test_conv3x3_eight_wave_tiles(cin, cout, hw, batch, pm, waves):
     check(f"8w fwd {cin}->{cout}@{hw} B{batch}", nchw(y), F.conv2d(nchw(x), oihw(w), b, padding=1))
 
 
+@pytest.mark.parametrize("batch", [3, 32, 256])
+@pytest.mark.parametrize("cin,cout,hw", [(64, 128, 16), (128, 256, 8), (256, 256, 8), (256, 512, 4),
+                                         (512, 512, 4), (512, 512, 2), (128, 128, 16)])
+@pytest.mark.parametrize("tile", [(256, 64, 20), (256, 64, 21), (128, 64, 20)])
+@pytest.mark.parametrize("kind", ["fwd", "fwd_relu", "dgrad", "dgrad_mask"])
+def test_conv3x3_tall_patch_tiles(batch, cin, cout, hw, tile, kind):
+    """Tall patch-resident tiles (conv_patch.hip): one LDS copy of a tile's pixels serves the nine
+    taps through the shift-invariant slot permutation, padding through the zero rows; forward with
+    both epilogues and backward-data with and without the ReLU mask, ragged last tiles included."""
+    n = native()
+    bm, bn, waves = tile
+    s = int(torch.cuda.current_stream().cuda_stream)
+    x = rand_bf16(batch, hw, hw, cin, seed=71)
+    w = rand_bf16(cout, 3, 3, cin, scale=(2.0 / (9 * cin)) ** 0.5, seed=72)
+    if kind.startswith("fwd"):
+        b = torch.randn(cout, device=DEV) * 0.1
+        y = torch.full((batch, hw, hw, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        epi = n.EPI_BIAS_RELU if kind == "fwd_relu" else n.EPI_BIAS
+        n.lib().conv3x3_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, 0, 0, batch,
+                              hw, cin, cout, epi, s, bm, bn, 1, 0, waves)
+        ref = F.conv2d(nchw(x), oihw(w), b, padding=1)
+        check(f"tall {kind} {cin}->{cout}@{hw} B{batch} {tile}", nchw(y),
+              ref.relu() if kind == "fwd_relu" else ref)
+    else:
+        dy = rand_bf16(batch, hw, hw, cout, seed=73)
+        wd = n.repack_dgrad(w)
+        dx = torch.full((batch, hw, hw, cin), float("nan"), dtype=torch.bfloat16, device=DEV)
+        mask = rand_bf16(batch, hw, hw, cin, seed=74).relu() if kind == "dgrad_mask" else None
+        n.lib().conv3x3_igemm(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), 0,
+                              mask.data_ptr() if mask is not None else 0, 0, 0, batch, hw, cout, cin,
+                              n.EPI_MASK if mask is not None else n.EPI_NONE, s, bm, bn, 1, 0, waves)
+        ref = torch.nn.grad.conv2d_input((batch, cin, hw, hw), oihw(w), nchw(dy), padding=1)
+        if mask is not None:
+            ref = ref * (nchw(mask) > 0)
+        check(f"tall {kind} {cin}->{cout}@{hw} B{batch} {tile}", nchw(dx), ref)
+
+
 @pytest.mark.parametrize("batch", [3, 32, 128])
 @pytest.mark.parametrize("cin,cout,hw", GENERIC_LAYERS)
 @pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64)])

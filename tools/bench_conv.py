@@ -47,8 +47,11 @@ def main():
         dw = torch.zeros(cout, 3, 3, cin, device=DEV)
         ws = torch.empty(9 * M * max(cin, cout), device=DEV)
         plans = [(128, 128, 1), (128, 64, 1), (64, 64, 1), (128, 128, 3), (128, 64, 3), (64, 64, 3),
-                 (64, 64, 9), (0, 0, 0)]
-        waves_opts = (4, 8, 9, 10, 16)
+                 (64, 64, 9), (0, 0, 0), (256, 64, 1)]
+        waves_opts = (4, 8, 9, 10, 16, 20, 21)
+        if os.environ.get("TALL_ONLY"):
+            plans = [(256, 64, 1), (128, 64, 1), (0, 0, 0)]
+            waves_opts = (4, 20, 21)
         for kind in which:
             if kind == "wgrad":
                 C.set_wgrad_variant(1)      # the one-tap-per-block kernel
@@ -83,7 +86,13 @@ def main():
             for (bm, bn, sp), pm, nw in itertools.product(plans, (0, 1), waves_opts):
                 if nw in (8, 9, 10) and (bm, bn) != (128, 128):
                     continue
-                if nw == 16 and (sp != 1 or pm or bm == 0):
+                if nw == 16 and (sp != 1 or pm or bm == 0 or bm == 256):
+                    continue
+                if nw >= 20 and (sp != 1 or pm or bn != 64 or hw > 16 or (bm, nw) == (128, 21)):
+                    continue
+                if bm == 256 and nw < 20:
+                    continue
+                if os.environ.get("TALL_ONLY") and nw == 4 and bm:
                     continue
                 n_out = cout if kind == "fwd" else cin
                 if bn and n_out % bn:
