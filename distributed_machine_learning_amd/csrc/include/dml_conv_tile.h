@@ -273,7 +273,10 @@ __device__ __forceinline__ void bn_plain_bwd_tile_sums(const f32x4 (&acc)[TN][TM
 // The patch-resident tall-tile kernels (conv_patch.hip): BM x 64 tiles, BM = 256 (variant 0: eight
 // waves of 64 x 32, variant 1: four waves of 64 x 64) or 128 (four waves of 64 x 32), hw 2 .. 16.
 bool conv3x3_pr_supported(int bm, int bn, int hw, int variant);
-void launch_pr(const IgemmArgs& a, int bm, int bn, int variant, int epi, hipStream_t stream);
+// splits > 1 (a power of two dividing cin / 64): the channel chunks are divided between that many
+// blocks per tile, each storing an fp32 slab [M][N] at a.slab + split * M * N (plain epilogue).
+void launch_pr(const IgemmArgs& a, int bm, int bn, int variant, int epi, int splits,
+               hipStream_t stream);
 
 }  // namespace igemm
 }  // namespace dml

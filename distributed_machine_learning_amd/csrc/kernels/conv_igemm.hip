@@ -474,7 +474,7 @@ struct Plan {
 // pay off together with the tap split.  The patch-resident kernel fetches 1.7x fewer bytes
 // but measures within +-10 % of the streaming one (LDS traffic, reads plus DMA writes, is
 // the next limit); it is used where it wins, the 64x64 plans.
-Plan choose_plan(int batch, int hw, int N, const int* force = nullptr) {
+Plan choose_plan(int batch, int hw, int N, int cin, const int* force = nullptr) {
     const int M = batch * hw * hw;
     // position-major tiles pay off where padding is a visible share of the taps and the
     // batch fills whole tiles
@@ -497,6 +497,9 @@ Plan choose_plan(int batch, int hw, int N, const int* force = nullptr) {
     if (tall_ok && hw <= 16 && hw >= 2) {
         if (blocks(256, 64) >= 256) return {256, 64, 1, false, 20};
         if (blocks(128, 64) >= 256) return {128, 64, 1, false, 20};
+        // half a block per CU: the channel chunks divided between two blocks per tile (fp32 slabs,
+        // summed by the consumer) - 256 -> 512 @ 4x4 backward-data
+        if (blocks(128, 64) * 2 >= 256 && cin >= 256) return {128, 64, 2, false, 20};
     }
     // (two LDS stages and two blocks per CU beat three stages and one: a second block's main
     // loop covers the first one's prologue and epilogue, which are a third of a block's life at
@@ -857,7 +860,7 @@ using namespace igemm;
 
 size_t conv3x3_igemm_workspace_elems(ConvShape s) {
     const int M = s.batch * s.hw * s.hw;
-    const Plan pl = choose_plan(s.batch, s.hw, s.cout);
+    const Plan pl = choose_plan(s.batch, s.hw, s.cout, s.cin);
     // room for the widest split so a forced plan (tuning) never outgrows the buffer
     return pl.splits > 1 ? (size_t)9 * M * s.cout : 0;
 }
@@ -865,7 +868,7 @@ size_t conv3x3_igemm_workspace_elems(ConvShape s) {
 int conv3x3_igemm_stats_rows(ConvShape s) {
     check_shape(s, "conv3x3_igemm_stats_rows");
     const int M = s.batch * s.hw * s.hw;
-    const Plan pl = choose_plan(s.batch, s.hw, s.cout);
+    const Plan pl = choose_plan(s.batch, s.hw, s.cout, s.cin);
     if (pl.splits > 1) return finish_stats_plan(M, s.cout).blocks;
     return pl.pm ? s.hw * s.hw * ((s.batch + pl.bm - 1) / pl.bm) : (M + pl.bm - 1) / pl.bm;
 }
@@ -901,7 +904,7 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
     a.M = s.batch * s.hw * s.hw; a.N = s.cout; a.C = s.cin;
     a.hw = s.hw; a.log_hw = ilog2(s.hw); a.log_chunks = ilog2(s.cin / 64);
     a.batch = s.batch; a.img_blocks = 0;
-    Plan pl = choose_plan(s.batch, s.hw, a.N, force_plan);
+    Plan pl = choose_plan(s.batch, s.hw, a.N, s.cin, force_plan);
     // The two-stage form is a forward choice: backward-data runs next to the weight-gradient
     // kernels of the side stream, and there one block per CU with a deeper ring measures better
     // inside the step (0.637 against 0.648 ms) although two blocks per CU win stand-alone.
@@ -909,7 +912,8 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
         pl.waves = pl.splits > 1 ? 9 : 8;
     const bool tall = pl.waves >= 20;       // the patch-resident tall tiles of conv_patch.hip
     if (tall) {
-        if (pl.splits != 1 || pl.pm || a.N % pl.bn || !conv3x3_pr_supported(pl.bm, pl.bn, s.hw, pl.waves - 20))
+        if (pl.splits < 1 || (pl.splits & (pl.splits - 1)) || pl.splits > s.cin / 64 || pl.pm ||
+            a.N % pl.bn || !conv3x3_pr_supported(pl.bm, pl.bn, s.hw, pl.waves - 20))
             throw std::invalid_argument("conv3x3_igemm: unsupported patch-resident tile plan");
     } else if (!((pl.bm == 128 || pl.bm == 64) && (pl.bn == 128 || pl.bn == 64) && a.N % pl.bn == 0 &&
           (pl.splits == 1 || pl.splits == 3 || pl.splits == 9)) || (pl.bm == 64 && pl.bn == 128))
@@ -933,7 +937,7 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
         *bn_done = BnPartials{bn_pool->partials, (a.M + pl.bm - 1) / pl.bm, nullptr};
     }
     if (tall) {
-        launch_pr(a, pl.bm, pl.bn, pl.waves - 20, epi, stream);
+        launch_pr(a, pl.bm, pl.bn, pl.waves - 20, epi, pl.splits, stream);
     } else if (pl.waves == 16) {
         if (pl.splits != 1 || pl.pm || pl.bm == pl.bn - 64)
             throw std::invalid_argument("conv3x3_igemm: the patch kernel has no split / "

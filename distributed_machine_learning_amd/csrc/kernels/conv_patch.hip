@@ -69,7 +69,7 @@ struct PatchGeom {
 
 }  // namespace
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OPT>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(IgemmArgs p) {
     raise_stream_signal(p);
     constexpr int NW = WAVES_M * WAVES_N;
@@ -94,7 +94,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int C = p.C, hw = p.hw;
-    const int chunks = 1 << p.log_chunks;
+    // (gridDim.y > 1: the 64-channel chunks of the reduction are divided between gridDim.y blocks
+    // per tile, each leaving an fp32 slab for the consumer to sum; plain epilogue only)
+    const int chunks = (1 << p.log_chunks) / (int)gridDim.y;      // this block's share
+    const int c0 = blockIdx.y * chunks;
     const int halo = hw + 1;
 
     // the zero rows of both patch buffers
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
 
     auto issue_patch = [&](int cc) {
         char* dst = smem + RING + (cc & 1) * PBUF + 256 + wave * 1024;
-        const int soff = cc * 128;
+        const int soff = (c0 + cc) * 128;
 #pragma unroll
         for (int i = 0; i < P_IT; ++i) {
             const int voff = p_off[i];
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
     };
     auto issue_w = [&](int cc, int row /* filter row = stage */) {
         char* dst = smem + row * WSTAGE + wave * 1024;
-        const int soff = (3 * row * C + cc * 64) * 2;
+        const int soff = (3 * row * C + (c0 + cc) * 64) * 2;
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) {
             const int voff = w_off[i];
@@ -183,12 +186,31 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
         constexpr int PAR = decltype(par_c)::value, U = decltype(u_c)::value;
         constexpr int T = U / 2, KX = (U & 1) * 32;
         constexpr int woff = (T / TPS) * WSTAGE + (T % TPS) * BN * 128;
+        // (the operand with fewer fragments first: the MFMAs walk i outer / j inner, so the first of
+        // them needs every pixel fragment but only the first weight fragment)
+        if constexpr (OPT & 1) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8*)(smem + ((wa[i] ^ KX) + woff));
+            for (int j = 0; j < TM; ++j)
+                xf[j] = *(const bf16x8*)(smem + ((pa[j][T] ^ KX) + PAR * PBUF));
 #pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *(const bf16x8*)(smem + ((pa[j][T] ^ KX) + PAR * PBUF));
+            for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8*)(smem + ((wa[i] ^ KX) + woff));
+        } else {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wf[i] = *(const bf16x8*)(smem + ((wa[i] ^ KX) + woff));
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                xf[j] = *(const bf16x8*)(smem + ((pa[j][T] ^ KX) + PAR * PBUF));
+        }
     };
     auto mma = [&](const bf16x8 (&wf)[TN], const bf16x8 (&xf)[TM]) {
+        if constexpr (OPT & 8) {
+            // (ablation build: fragments are read and kept alive, nothing is multiplied)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+            for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(xf[j]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -200,6 +222,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
     // fragment read down to its first use and the register double buffer is gone): the reads of
     // the NEXT sub-step alternate with the MFMAs of this one.
     auto interleave = [&]() {
+        if constexpr (OPT & 8) return;
 #pragma unroll
         for (int k = 0; k < TN + TM; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, (TN * TM) / (TN + TM), 0);   // MFMA
@@ -231,7 +254,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
         constexpr bool LAST = decltype(last_c)::value != 0;
         auto after_barrier = [&](auto i_c) {          // loads issued behind the barrier of stage i
             constexpr int I = decltype(i_c)::value;
-            if constexpr (!LAST) {
+            if constexpr (OPT & 4) {
+                // (ablation build: no copies in the loop - the operands are whatever LDS holds)
+            } else if constexpr (!LAST) {
                 if constexpr (I == 0) { issue_w(cc, 2); issue_patch(cc + 1); }
                 else issue_w(cc + 1, I - 1);
             } else {
@@ -242,7 +267,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
         };
         auto wait_for_next = [&](auto i_c) {          // before the barrier of the stage after (cc, i)
             constexpr int I = decltype(i_c)::value;
-            if constexpr (!LAST) {
+            if constexpr (OPT & 4) {
+                wait_vmcnt<0>();
+            } else if constexpr (!LAST) {
                 if constexpr (I < 2) wait_vmcnt<W_IT + P_IT>();
                 else wait_vmcnt<W_IT>();
             } else {
@@ -283,6 +310,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
         stage(ic<2>{});
     };
 
+    if constexpr (OPT & 2) {     // the later-dispatched half loses every arbitration otherwise
+        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+    }
     issue_patch(0);
     issue_w(0, 0);
     issue_w(0, 1);
@@ -303,7 +333,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
     }
 
     // ---- BatchNorm sums for free, one partial row [2][N] per pixel tile (see conv_igemm.hip)
-    const bool bn_bwd = EPI == EPI_NONE && p.bn_pre != nullptr;
+    const bool bn_bwd = EPI == EPI_NONE && p.bn_pre != nullptr && gridDim.y == 1;
     if (p.stats && (EPI == EPI_BIAS || bn_bwd)) {
         float s1[TN][4], s2[TN][4];
         if (bn_bwd) {
@@ -359,6 +389,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
         const int m = m0 + wm * WTM + j * 16 + l15;
         if (m >= p.M) continue;
         const int n = n0 + wn * WTN + lq * 4 * TN;
+        if constexpr (EPI == EPI_NONE) {
+            if (gridDim.y > 1) {
+                float* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.N + n;
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+                    *(float4*)(dst + 4 * i) =
+                        float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                continue;
+            }
+        }
         f32x4 a[TN];
 #pragma unroll
         for (int i = 0; i < TN; ++i) a[i] = acc[i][j];
@@ -368,47 +408,66 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv3x3_pr_kernel(Igem
 
 namespace {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
-void launch_pr_one(const IgemmArgs& a, hipStream_t stream) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OPT>
+void launch_pr_one(const IgemmArgs& a, int splits, hipStream_t stream) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int lds = kStages * kTapsPerStage * BN * 128 + 2 * PatchGeom<BM, NW>::kBytes;
     static_assert(lds <= 160 * 1024, "tile does not fit the CU's LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_pr_kernel<BM, BN, WAVES_M, WAVES_N, EPI>,
+        (void)hipFuncSetAttribute((const void*)conv3x3_pr_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OPT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const dim3 grid(((a.M + BM - 1) / BM) * a.tiles_n);
-    hipLaunchKernelGGL((conv3x3_pr_kernel<BM, BN, WAVES_M, WAVES_N, EPI>), grid, dim3(NW * 64), lds,
+    const dim3 grid(((a.M + BM - 1) / BM) * a.tiles_n, splits);
+    hipLaunchKernelGGL((conv3x3_pr_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OPT>), grid, dim3(NW * 64), lds,
                        stream, a);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-void launch_pr_epi(const IgemmArgs& a, int epi, hipStream_t stream) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OPT>
+void launch_pr_epi(const IgemmArgs& a, int epi, int splits, hipStream_t stream) {
+    if (splits > 1) {
+        launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_NONE, OPT>(a, splits, stream);
+        return;
+    }
     switch (epi) {
-        case EPI_NONE: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_NONE>(a, stream); break;
-        case EPI_BIAS: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_BIAS>(a, stream); break;
-        case EPI_BIAS_RELU: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_BIAS_RELU>(a, stream); break;
-        default: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_MASK>(a, stream); break;
+        case EPI_NONE: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_NONE, OPT>(a, 1, stream); break;
+        case EPI_BIAS: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_BIAS, OPT>(a, 1, stream); break;
+        case EPI_BIAS_RELU: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_BIAS_RELU, OPT>(a, 1, stream); break;
+        default: launch_pr_one<BM, BN, WAVES_M, WAVES_N, EPI_MASK, OPT>(a, 1, stream); break;
     }
 }
 
 }  // namespace
 
 bool conv3x3_pr_supported(int bm, int bn, int hw, int variant) {
-    if (hw > 16 || hw < 2 || bn != 64) return false;
-    if (bm == 256) return variant == 0 || variant == 1;
-    if (bm == 128) return variant == 0;
+    if (hw > 16 || hw < 2 || bn != 64 || variant < 0) return false;
+    const int four = variant & 1, opt = variant >> 1;
+    if (opt > 3) return false;
+    if (bm == 256) return !(four && opt);
+    if (bm == 128) return !four;
     return false;
 }
 
-void launch_pr(const IgemmArgs& a, int bm, int bn, int variant, int epi, hipStream_t stream) {
-    if (!conv3x3_pr_supported(bm, bn, a.hw, variant))
+// variant: bit 0 = four waves of 64 x 64 (256-row tiles only), bits 1.. = tuning options
+void launch_pr(const IgemmArgs& a, int bm, int bn, int variant, int epi, int splits,
+               hipStream_t stream) {
+    if (!conv3x3_pr_supported(bm, bn, a.hw, variant) || splits < 1 || (splits & (splits - 1)) ||
+        splits > (1 << a.log_chunks) || (splits > 1 && !a.slab))
         throw std::invalid_argument("conv3x3_igemm: unsupported patch-resident tile");
-    if (bm == 256 && variant == 0) launch_pr_epi<256, 64, 8, 1>(a, epi, stream);
-    else if (bm == 256) launch_pr_epi<256, 64, 4, 1>(a, epi, stream);
-    else launch_pr_epi<128, 64, 4, 1>(a, epi, stream);
+    const int opt = variant >> 1;
+    if (bm == 256 && (variant & 1)) launch_pr_epi<256, 64, 4, 1, 0>(a, epi, splits, stream);
+    else if (bm == 256) {
+        if (opt == 0) launch_pr_epi<256, 64, 8, 1, 0>(a, epi, splits, stream);
+        else if (opt == 1) launch_pr_epi<256, 64, 8, 1, 4>(a, epi, splits, stream);
+        else if (opt == 2) launch_pr_epi<256, 64, 8, 1, 8>(a, epi, splits, stream);
+        else launch_pr_epi<256, 64, 8, 1, 12>(a, epi, splits, stream);
+    } else {
+        if (opt == 0) launch_pr_epi<128, 64, 4, 1, 0>(a, epi, splits, stream);
+        else if (opt == 1) launch_pr_epi<128, 64, 4, 1, 4>(a, epi, splits, stream);
+        else if (opt == 2) launch_pr_epi<128, 64, 4, 1, 8>(a, epi, splits, stream);
+        else launch_pr_epi<128, 64, 4, 1, 12>(a, epi, splits, stream);
+    }
 }
 
 }  // namespace igemm

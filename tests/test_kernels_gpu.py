@@ -157,6 +157,29 @@ def test_conv3x3_tall_patch_tiles(batch, cin, cout, hw, tile, kind):
         check(f"tall {kind} {cin}->{cout}@{hw} B{batch} {tile}", nchw(dx), ref)
 
 
+@pytest.mark.parametrize("batch", [5, 256])
+@pytest.mark.parametrize("cin,cout,hw", [(128, 256, 8), (512, 256, 4), (512, 512, 2)])
+@pytest.mark.parametrize("tile", [(256, 64), (128, 64)])
+@pytest.mark.parametrize("splits", [2, 4])
+def test_conv3x3_tall_tiles_chunk_split(batch, cin, cout, hw, tile, splits):
+    """Tall tiles with the channel chunks divided between `splits` blocks per tile (fp32 slabs
+    summed by the finishing kernel, which also applies the epilogue)."""
+    n = native()
+    bm, bn = tile
+    if splits > cin // 64:
+        pytest.skip("more splits than channel chunks")
+    s = int(torch.cuda.current_stream().cuda_stream)
+    x = rand_bf16(batch, hw, hw, cin, seed=81)
+    w = rand_bf16(cout, 3, 3, cin, scale=(2.0 / (9 * cin)) ** 0.5, seed=82)
+    b = torch.randn(cout, device=DEV) * 0.1
+    ws = torch.empty(9 * batch * hw * hw * cout, device=DEV)
+    y = torch.full((batch, hw, hw, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    n.lib().conv3x3_igemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), 0, ws.data_ptr(),
+                          ws.numel(), batch, hw, cin, cout, n.EPI_BIAS_RELU, s, bm, bn, splits, 0, 20)
+    ref = F.conv2d(nchw(x), oihw(w), b, padding=1).relu()
+    check(f"tall split fwd {cin}->{cout}@{hw} B{batch} {tile}/{splits}", nchw(y), ref)
+
+
 @pytest.mark.parametrize("batch", [3, 32, 128])
 @pytest.mark.parametrize("cin,cout,hw", GENERIC_LAYERS)
 @pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64)])
