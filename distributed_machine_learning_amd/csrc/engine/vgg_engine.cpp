@@ -115,6 +115,10 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
     if (max_batch <= 0) throw std::invalid_argument("VggEngine: batch must be positive");
     if (const char* e = getenv("DML_BN_EPI_SUMS")) plain_epi_sums_ = atoi(e) != 0;      // tuning
     if (const char* e = getenv("DML_WGRAD_TUNED")) tuned_wgrad_splits_ = atoi(e) != 0;  // tuning
+    // Timing experiment, never a training mode: the weight-gradient kernels (and slab sums) of the
+    // conv layers whose bit is set (bit i = layer i, 1 = all) are not launched and their gradients
+    // stay stale, which shows what the main chain takes without them.
+    if (const char* e = getenv("DML_EXPERIMENT_NO_WGRAD")) experiment_no_wgrad_ = atoi(e);
     const ParamLayout lay = plan_parameters(widths, batch_norm, num_classes);
     for (const ParamLayout::Conv& l : lay.convs) {
         Conv c;
@@ -396,6 +400,7 @@ void VggEngine::launch_wgrad(int i, int batch, hipStream_t stream) {
     // noise), so it is left at the zero the buffer was allocated with.  Without BatchNorm
     // nothing else in a backward pass touches the reduction scratch.
     if (!bn_) column_sum(g, grads_ + c.b_off, batch * c.hw * c.hw, c.cout, ws_ + stats_off_, stream);
+    if (experiment_no_wgrad_ == 1 || ((experiment_no_wgrad_ >> i) & 1)) return;
     const int target = wgrad_split_target();
     // pixel splits: the tuning override, else the list tuned inside the step for this shape, else
     // the kernel's plan for the block target

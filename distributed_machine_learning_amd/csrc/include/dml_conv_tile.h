@@ -270,8 +270,9 @@ __device__ __forceinline__ void bn_plain_bwd_tile_sums(const f32x4 (&acc)[TN][TM
         }
 }
 
-// The patch-resident tall-tile kernels (conv_patch.hip): BM x 64 tiles, BM = 256 (variant 0: eight
-// waves of 64 x 32, variant 1: four waves of 64 x 64) or 128 (four waves of 64 x 32), hw 2 .. 16.
+// The patch-resident tall-tile kernels (conv_patch.hip): BM x 64 tiles, BM = 256 or 128, eight
+// waves, hw 2 .. 16.  variant 0: the shipped wave layout of the tile height, 1: the other layout,
+// 2 .. 4: ablation builds for timing only, 5 (128 rows): four waves.
 bool conv3x3_pr_supported(int bm, int bn, int hw, int variant);
 // splits > 1 (a power of two dividing cin / 64): the channel chunks are divided between that many
 // blocks per tile, each storing an fp32 slab [M][N] at a.slab + split * M * N (plain epilogue).

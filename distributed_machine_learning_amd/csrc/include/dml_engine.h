@@ -211,6 +211,7 @@ class VggEngine {
     bool side_done_by_value_ = false;       // ... and this backward pass has raised it that way
     std::vector<int> wgrad_queue_;          // layers whose gradient is ready, wgrad not yet launched
     bool tuned_wgrad_splits_ = true;        // use conv3x3_wgrad_tuned_splits where it has an entry
+    int experiment_no_wgrad_ = 0;           // timing experiment (wrong gradients): see the constructor
     // tuning (DML_DGRAD_PLANS): backward-data plan {bm, bn, splits, pm, waves} per conv layer, bm 0 = default
     std::vector<std::array<int, 5>> dgrad_force_plan_;
     // forward of the 2x2 layers under BatchNorm: split-K finish + statistics + apply in one launch

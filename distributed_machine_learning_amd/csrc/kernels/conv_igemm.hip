@@ -36,6 +36,7 @@
 //     small finishing kernel sums the slabs and applies the epilogue (deterministic,
 //     no atomics).
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 
@@ -462,8 +463,7 @@ struct Plan {
     int waves;      // 4, 8 (3 LDS stages), 9 = eight waves with 4 LDS stages (tuning),
                     // 10 = eight waves with 2 LDS stages (64 KiB: two blocks per CU),
                     // 16 = patch-resident kernel (eight waves for 128-row tiles, four for 64),
-                    // 20 / 21 = tall patch-resident tiles of conv_patch.hip (BM x 64; 21: 256 x 64
-                    // run by four waves of 64 x 64)
+                    // 20 + v = tall patch-resident tiles of conv_patch.hip (BM x 64), variant v
 };
 
 // Tile / split choice, from per-layer timings on MI355X at batch 256 (tools/bench_conv.py).
@@ -494,12 +494,19 @@ Plan choose_plan(int batch, int hw, int N, int cin, const int* force = nullptr) 
         const char* e = getenv("DML_TALL_TILES");
         return !(e && e[0] == '0');
     }();
+    // (tuning: DML_TALL_VARIANT="v256,v128" picks the kernel variant per tile height)
+    static const int v256 = [] { const char* e = getenv("DML_TALL_VARIANT"); return e ? atoi(e) : 0; }();
+    static const int v128 = [] {
+        const char* e = getenv("DML_TALL_VARIANT");
+        const char* c = e ? strchr(e, ',') : nullptr;
+        return c ? atoi(c + 1) : 0;
+    }();
     if (tall_ok && hw <= 16 && hw >= 2) {
-        if (blocks(256, 64) >= 256) return {256, 64, 1, false, 20};
-        if (blocks(128, 64) >= 256) return {128, 64, 1, false, 20};
+        if (blocks(256, 64) >= 256) return {256, 64, 1, false, 20 + v256};
+        if (blocks(128, 64) >= 256) return {128, 64, 1, false, 20 + v128};
         // half a block per CU: the channel chunks divided between two blocks per tile (fp32 slabs,
         // summed by the consumer) - 256 -> 512 @ 4x4 backward-data
-        if (blocks(128, 64) * 2 >= 256 && cin >= 256) return {128, 64, 2, false, 20};
+        if (blocks(128, 64) * 2 >= 256 && cin >= 256) return {128, 64, 2, false, 20 + v128};
     }
     // (two LDS stages and two blocks per CU beat three stages and one: a second block's main
     // loop covers the first one's prologue and epilogue, which are a third of a block's life at

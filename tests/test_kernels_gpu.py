@@ -123,7 +123,7 @@ def test_conv3x3_eight_wave_tiles(cin, cout, hw, batch, pm, waves):
 @pytest.mark.parametrize("batch", [3, 32, 256])
 @pytest.mark.parametrize("cin,cout,hw", [(64, 128, 16), (128, 256, 8), (256, 256, 8), (256, 512, 4),
                                          (512, 512, 4), (512, 512, 2), (128, 128, 16)])
-@pytest.mark.parametrize("tile", [(256, 64, 20), (256, 64, 21), (128, 64, 20)])
+@pytest.mark.parametrize("tile", [(256, 64, 20), (256, 64, 21), (128, 64, 20), (128, 64, 21), (128, 64, 25)])
 @pytest.mark.parametrize("kind", ["fwd", "fwd_relu", "dgrad", "dgrad_mask"])
 def test_conv3x3_tall_patch_tiles(batch, cin, cout, hw, tile, kind):
     """Tall patch-resident tiles (conv_patch.hip): one LDS copy of a tile's pixels serves the nine

@@ -51,7 +51,7 @@ def main():
         waves_opts = (4, 8, 9, 10, 16, 20, 21)
         if os.environ.get("TALL_ONLY"):
             plans = [(256, 64, 1), (128, 64, 1), (0, 0, 0)]
-            waves_opts = (4, 20, 21, 22, 24, 26)
+            waves_opts = (4, 20, 21, 22, 23, 24, 25)
         for kind in which:
             if kind == "wgrad":
                 C.set_wgrad_variant(1)      # the one-tap-per-block kernel
@@ -88,7 +88,7 @@ def main():
                     continue
                 if nw == 16 and (sp != 1 or pm or bm == 0 or bm == 256):
                     continue
-                if nw >= 20 and (sp != 1 or pm or bn != 64 or hw > 16 or (bm == 128 and nw & 1)):
+                if nw >= 20 and (sp != 1 or pm or bn != 64 or hw > 16 or (bm == 256 and nw == 25)):
                     continue
                 if bm == 256 and nw < 20:
                     continue

@@ -29,9 +29,16 @@ def main():
     ccol = idx["counter_name"]
     gcol = idx.get("grid_size", idx.get("grid_size_x"))
     table = defaultdict(lambda: defaultdict(list))
+    seen = set()
     for r in rows:
         key = (short(str(r[kcol])), r[gcol] if gcol is not None else 0)
         table[key][r[ccol]].append(float(r[idx["value"]]))
+        # wall time of the dispatch (ns -> us), once per dispatch, where the database has it
+        if "start" in idx and "end" in idx and "dispatch_id" in idx:
+            d = r[idx["dispatch_id"]]
+            if d not in seen and r[idx["start"]] and r[idx["end"]]:
+                seen.add(d)
+                table[key]["~wall_us"].append((float(r[idx["end"]]) - float(r[idx["start"]])) / 1e3)
     counters = sorted({c for v in table.values() for c in v})
     print(f"{'kernel':60s} {'grid':>9s} " + " ".join(f"{c[-22:]:>22s}" for c in counters))
     for (name, grid), v in sorted(table.items()):
