@@ -119,6 +119,15 @@ def parse(argv=None):
     ap.add_argument("--dry-launch", action="store_true",
                     help="self-launch check: every rank prints its launcher environment and "
                          "exits without touching a GPU")
+    ap.add_argument("--self-checks", choices=("auto", "on", "off"), default="auto",
+                    help="numerical self-checks on the live communicator, outside the timed region "
+                         "(auto: with more than one rank): flag-word against event hand-offs bit for "
+                         "bit, data parallelism against rank 0 alone on the global batch in all "
+                         "three sync modes, an fp32 window and a bf16-wire window")
+    ap.add_argument("--bucket-departure", choices=("auto", "event", "value"), default="auto",
+                    help="part3: how a gradient bucket is handed to the communication stream.  auto: "
+                         "the reducer's own default, upgraded to flag words when the self-check has "
+                         "just shown them bit-identical to event pairs on this communicator")
     ap.add_argument("--profile-ranges", action="store_true",
                     help="emit roctx ranges for the phases of the step (rocprofv3 --marker-trace)")
     return ap.parse_args(argv)
@@ -299,6 +308,32 @@ def run_rank(ns) -> None:
             backend.comm_only_step()
         barrier()
 
+    # ---- which form of hand-off the timed run uses (outside the timed region).  With RCCL and
+    # more than one rank the reducer starts on event pairs; when flag words reproduce their result
+    # bit for bit on THIS communicator the run switches to them.
+    checks_on = ns.self_checks == "on" or (ns.self_checks == "auto" and world > 1)
+    self_checks = {}
+    checks_failed = []
+    native_ddp = backend.name == "native" and getattr(backend, "reducer", None) is not None
+    if native_ddp and ns.bucket_departure != "auto":
+        backend.reducer.set_departure_by_value(ns.bucket_departure == "value")
+    if native_ddp and checks_on and backend.reducer.can_depart_by_value:
+        try:
+            from distributed_machine_learning_amd.utils.selfcheck import handoff_forms_agree
+            res = handoff_forms_agree(backend, comm, batches, steps=3)
+            self_checks["handoff_forms"] = res
+            if not res["ok"]:
+                checks_failed.append("handoff_forms")
+                backend.reducer.set_departure_by_value(False)
+            elif ns.bucket_departure == "auto" and not os.environ.get("DML_REDUCER_HANDOFF"):
+                # proven equal on this very job: the cheaper form carries the timed steps
+                # (an explicit DML_REDUCER_HANDOFF stays what the caller asked for)
+                backend.reducer.set_departure_by_value(True)
+        except Exception as exc:                # noqa: BLE001 - reported in the record
+            self_checks["handoff_forms"] = {"ok": False, "error": f"{type(exc).__name__}: {exc}"}
+            checks_failed.append("handoff_forms")
+        barrier()
+
     if ns.prime_steps > 0 and hasattr(backend, "prime"):
         backend.prime(batches, ns.prime_steps)
         barrier()
@@ -352,12 +387,51 @@ def run_rank(ns) -> None:
         if comm is not None and (world > 1 or ns.report_overlap):
             from distributed_machine_learning_amd.utils.overlap import measure_comm_split
             overlap = measure_comm_split(backend, comm, batches, n=max(10, min(ns.steps, 50)))
+
+        # ---- correctness against an independent computation (see utils/selfcheck.py)
+        if comm is not None and checks_on and backend.name == "native":
+            from distributed_machine_learning_amd.utils import selfcheck
+            res = selfcheck.dp_and_manual_modes(cfg.replace(dtype=ns.dtype), comm, device,
+                                                backend.loader_layout)
+            self_checks["data_parallel"] = res
+            if not res["ok"]:
+                checks_failed.append("data_parallel")
     except Exception as exc:                    # noqa: BLE001 - reported, then the run fails
         extras_error = f"{type(exc).__name__}: {exc}"
         print(f"[bench] rank {rank}: after the measured region: {extras_error}", file=sys.stderr)
         if comm is not None and len(per_rank_ms) == 1 and world > 1:
             # the MAX over ranks could not be taken: say so instead of passing off one rank's time
             extras_error += " (ms_per_step is rank 0's own time, not the maximum over ranks)"
+
+    # ---- optional extra windows (never fatal): the reference's precision and bf16 on the wire
+    extra_windows = {}
+    if comm is not None and checks_on and backend.name == "native" and extras_error is None:
+        from distributed_machine_learning_amd.utils import selfcheck
+
+        def batches_for(layout):
+            t2 = BatchTransform(True, layout, SEED)
+            out = []
+            for i in range(2):
+                idx = torch.arange(ns.batch_size, device=device) * world + rank + i * ns.batch_size * world
+                imgs, labels = ds.take(idx)
+                out.append((t2(imgs, idx).contiguous(), labels.contiguous()))
+            return out
+
+        for name, over in (("fp32", {"dtype": "fp32"}),
+                           ("bf16_wire", {"dtype": "bf16", "grad_comm_dtype": "bf16"})):
+            if name == "bf16_wire" and (sync != "ddp" or ns.dtype != "bf16"):
+                continue
+            if name == "fp32" and ns.dtype == "fp32":
+                continue
+            try:
+                extra_windows[name + "_ms_per_step"] = selfcheck.timed_window(
+                    cfg, comm, device, batches_for, steps=20, warmup=5, **over)
+            except Exception as exc:            # noqa: BLE001
+                extra_windows[name + "_error"] = f"{type(exc).__name__}: {exc}"
+        try:
+            extra_windows["transport"] = selfcheck.transport_facts()
+        except Exception as exc:                # noqa: BLE001
+            extra_windows["transport_error"] = f"{type(exc).__name__}: {exc}"
 
     if rank == 0:
         ms = elapsed / ns.steps * 1e3
@@ -374,10 +448,20 @@ def run_rank(ns) -> None:
             "rccl_nranks": nranks_seen, "transport": ns.transport if comm is not None else "none",
             "per_rank_ms_per_step": per_rank_ms, "params_in_sync": in_sync,
             "extras_error": extras_error,
-            # bytes rank 0 put on / took off its links per step (ring all-reduce, direct
-            # gather / scatter), from the collectives issued inside the measured region
-            # (its two barriers' 4-byte tokens included)
-            "comm_bytes_per_step": ({"tx": volume["tx_bytes"] // ns.steps,
+            # numerical self-checks on the live communicator (utils/selfcheck.py): None = not run
+            "handoff_bitwise_ok": (self_checks.get("handoff_forms") or {}).get("ok"),
+            "dp_vs_single_rel_err": ({m: v["rel_err_vs_single"] for m, v in
+                                      self_checks["data_parallel"]["modes"].items()}
+                                     if "data_parallel" in self_checks else None),
+            "self_checks": self_checks or None,
+            "self_checks_failed": checks_failed or None,
+            "extras": extra_windows or None,
+            # MODELLED bytes rank 0 puts on / takes off its links per step - ring all-reduce,
+            # direct gather / scatter - computed from the collectives issued inside the measured
+            # region (its two barriers' 4-byte tokens included); not a hardware link counter, and
+            # RCCL may run another algorithm
+            "comm_bytes_per_step": ({"model": "ring all-reduce, direct gather/scatter",
+                                     "tx": volume["tx_bytes"] // ns.steps,
                                      "rx": volume["rx_bytes"] // ns.steps,
                                      "calls": {k: v for k, v in volume["calls"].items() if v}}
                                     if volume is not None else None),
@@ -404,14 +488,17 @@ def run_rank(ns) -> None:
     if extras_error is not None:
         # The measured region itself completed on every rank (its closing barrier returned), so
         # the record stands and says what failed afterwards.  A failed collective may have left
-        # the communicator unusable: no orderly teardown.
+        # the communicator unusable: no orderly teardown.  With more than one rank a run whose
+        # cross-rank checks could not be completed is NOT a verified number: non-zero exit.
         sys.stderr.flush()
-        os._exit(1 if in_sync is False else 0)
+        os._exit(1 if (in_sync is False or (world > 1 and in_sync is not True)) else 0)
     backend.close()
     if comm is not None:
         comm.destroy()
     if in_sync is False:
         raise SystemExit("parameters differ between ranks after the timed loop")
+    if checks_failed:
+        raise SystemExit(f"self-checks failed: {', '.join(checks_failed)} (see the record)")
 
 
 def main(argv=None) -> int:

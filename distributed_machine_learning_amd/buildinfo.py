@@ -16,8 +16,14 @@ ARCH = "gfx950"
 
 # Flags every translation unit gets (machine-specific include paths are added by build.py and
 # are not part of the hash).
+# -fno-slp-vectorize: no packed fp32 VALU pairs (v_pk_fma_f32 and friends) formed from scalar
+# code.  With them the one-launch BatchNorm backward kernel (bn_bwd_slab_kernel) took wrong
+# compare masks in lanes 48-63 of a wave about once in a hundred launches while a second process
+# shared the GPU (tools/probes/flake_ddp_bn.py: 7 expected in 660 two-rank runs, none without the
+# packed ops; no documented wait-state rule is violated in the generated code).  The step is also
+# 1.2 % faster without them (0.592 -> 0.585 ms on one box, tools/probes/ab_noslp.sh).
 COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
-                "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
+                "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__", "-fno-slp-vectorize"]
 
 # Per-file device-code flags.  No -ffast-math anywhere: the kernels call the fast intrinsics
 # they want by name (rsqrtf, __expf) and the reductions rely on a fixed summation order for

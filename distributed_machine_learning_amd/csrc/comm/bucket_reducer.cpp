@@ -6,7 +6,8 @@
 // are grouped into buckets in reverse parameter order and each bucket's all-reduce is
 // started as soon as backward has produced its last gradient, overlapping the rest of
 // backward.  Here a bucket is a slice of the flat gradient buffer, the all-reduce runs in
-// place on a dedicated HIP stream, and ordering is expressed with HIP events only.
+// place on a dedicated HIP stream, and a bucket departs / reports back either through a flag
+// word and a wait-value packet or through an event pair (see BucketReducer's constructor).
 #include <cstring>
 #include <cstdlib>
 #include <pybind11/pybind11.h>
@@ -41,9 +42,11 @@ std::vector<BucketRange> plan_buckets(const std::vector<size_t>& sizes_bytes, si
 }
 
 namespace {
-// Default release scope on purpose (no hipEventReleaseToDevice): the "ready" event is what makes
-// the gradients this GPU's kernels just wrote visible beyond its own L2 - with more than one
-// rank, peers read a bucket straight out of this GPU's memory over xGMI.
+// Event-pair departures keep the default (system) release scope on purpose, no
+// hipEventReleaseToDevice: with more than one rank, peers read a bucket straight out of this
+// GPU's memory over xGMI, and the "ready" event's release is what is documented to make this
+// GPU's writes visible beyond the device.  (The flag-word departure relies on the release every
+// kernel performs as it ends instead; see the constructor for where each form is the default.)
 constexpr unsigned kEventFlags = hipEventDisableTiming;
 
 void check_hip(hipError_t e, const char* what) {
@@ -77,23 +80,42 @@ BucketReducer::BucketReducer(Comm* comm, float* flat_grads, std::vector<Slice> s
     // A stream that waits for an EVENT of another queue costs the step ~6.5 us per bucket on
     // MI355X / ROCm 7 (measured at one rank by leaving the wait out: the marker alone costs
     // 1.7 us, marker + wait 8 us, tools/ab_reducer_probe.sh).  Where the device can wait for a
-    // value in memory, a bucket departs through a flag word instead: a one-wave kernel behind
+    // value in memory, a bucket can depart through a flag word instead: a one-wave kernel behind
     // the bucket's last gradient kernel raises it - every earlier kernel of that queue has then
-    // completed and written its results back, which is all the local RCCL kernel and its peers
-    // (who read device memory over xGMI, never this GPU's L2) need - and the communication
-    // stream holds a wait-value packet.  DML_REDUCER_HANDOFF=event keeps the event pair.
-    int can_wait_value = 0, device = 0;
+    // completed and released its writes - and the communication stream holds a wait-value packet.
+    //
+    // Which form is the default.  Inside one GPU (one rank, or the loopback test transport, whose
+    // payload travels through the host) the flag word has been shown bit-identical to the event
+    // pair.  Over xGMI the peers of an RCCL all-reduce read this GPU's gradients remotely, and that
+    // the end-of-kernel release covers such a reader has not been observed on a multi-GPU node
+    // from this code yet: with RCCL and more than one rank the event pair (system-scope release)
+    // stays the default until a run has compared the two - bench.py does that comparison at the
+    // start of every multi-rank run and switches to flag words when they reproduce the event
+    // pair's parameters bit for bit (set_departure_by_value).  DML_REDUCER_HANDOFF=event | value
+    // forces one form.
+    int device = 0;
     if (!serialize_ && hipGetDevice(&device) == hipSuccess)
-        (void)hipDeviceGetAttribute(&can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device);
+        (void)hipDeviceGetAttribute(&can_wait_value_, hipDeviceAttributeCanUseStreamWaitValue, device);
     const char* mode = getenv("DML_REDUCER_HANDOFF");
-    by_value_ = can_wait_value && !(mode && !strcmp(mode, "event"));
-    if (by_value_) {
+    const bool remote_readers = comm_->world_size() > 1 && !strcmp(comm_->transport(), "rccl");
+    bool by_value = can_wait_value_ && !remote_readers;
+    if (mode && !strcmp(mode, "event")) by_value = false;
+    if (mode && !strcmp(mode, "value")) by_value = can_wait_value_ != 0;
+    set_departure_by_value(by_value);
+}
+
+void BucketReducer::set_departure_by_value(bool on) {
+    if (on && (!can_wait_value_ || serialize_))
+        throw std::logic_error("BucketReducer: flag-word departures need wait-value support and "
+                               "a communication stream");
+    if (on && !ready_flags_) {
         // (word b: bucket b's gradients are complete; word n + b: its all-reduce is complete)
         const size_t bytes = 2 * slices_.size() * sizeof(unsigned);
         check_hip(hipMalloc((void**)&ready_flags_, bytes), "hipMalloc(bucket flags)");
         check_hip(hipMemset(ready_flags_, 0, bytes), "hipMemset(bucket flags)");
         check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(bucket flags)");
     }
+    by_value_ = on;
 }
 
 BucketReducer::~BucketReducer() {
@@ -185,12 +207,16 @@ void BucketReducer::reduce_slice(int b, hipStream_t stream) {
         n = (size_t)(buffers_staging_ - base);
         tail = s.count - n;
     }
-    cast_f32_to_bf16(base, wire_ + s.offset, n, stream);
+    // (the conversion kernels move four elements per thread: up to three gradients at the end of
+    // a slice of any other length join the fp32 part)
+    tail += n & 3;
+    n -= n & 3;
+    if (n) cast_f32_to_bf16(base, wire_ + s.offset, n, stream);
     comm_->group_start();
-    comm_->all_reduce(wire_ + s.offset, n, DT_BF16, false, stream);
+    if (n) comm_->all_reduce(wire_ + s.offset, n, DT_BF16, false, stream);
     if (tail) comm_->all_reduce(base + n, tail, DT_F32, false, stream);
     comm_->group_end();
-    cast_bf16_to_f32(wire_ + s.offset, base, n, stream);
+    if (n) cast_bf16_to_f32(wire_ + s.offset, base, n, stream);
 }
 
 void BucketReducer::wait_all(hipStream_t compute) {
@@ -284,6 +310,7 @@ void bind_comm(py::module_& m) {
         .def_property_readonly("port", &TcpStore::port);
 
     m.def("rccl_unique_id", []() { return py::bytes(RcclComm::unique_id()); });
+    m.def("rccl_version", &RcclComm::version);
 
     m.def("link_bytes", [](int kind, uint64_t payload, int world, bool is_root) {
         uint64_t tx = 0, rx = 0;
@@ -346,7 +373,11 @@ void bind_comm(py::module_& m) {
             std::string id = uid;
             py::gil_scoped_release rel;
             return new RcclComm(id, rank, world, device);
-        }));
+        }))
+        .def("self_exchange", [](RcclComm& c, uintptr_t src, uintptr_t dst, size_t n, int dt,
+                                 uintptr_t s) {
+            c.self_exchange((const void*)src, (void*)dst, n, (DType)dt, (hipStream_t)s);
+        });
 
     py::class_<LoopbackComm, Comm>(m, "LoopbackComm")
         .def(py::init([](const std::string& name, int rank, int world, int device, double timeout) {
@@ -408,6 +439,8 @@ void bind_comm(py::module_& m) {
         .def_property("inline_last", &BucketReducer::inline_last, &BucketReducer::set_inline_last)
         .def_property_readonly("departure_mode",
                                [](BucketReducer& r) { return std::string(r.departure_mode()); })
+        .def_property_readonly("can_depart_by_value", &BucketReducer::can_depart_by_value)
+        .def("set_departure_by_value", &BucketReducer::set_departure_by_value)
         .def_property_readonly("comm_stream",
                                [](BucketReducer& r) { return (uintptr_t)r.comm_stream(); });
 }

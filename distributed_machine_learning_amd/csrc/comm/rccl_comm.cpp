@@ -80,6 +80,23 @@ std::string RcclComm::unique_id() {
     return std::string((const char*)&id, sizeof(id));
 }
 
+int RcclComm::version() {
+    int v = 0;
+    check_nccl(ncclGetVersion(&v), "ncclGetVersion");
+    return v;
+}
+
+void RcclComm::self_exchange(const void* src, void* dst, size_t count, DType dt,
+                             hipStream_t stream) {
+    if (!comm_) throw std::logic_error("RcclComm: communicator destroyed");
+    if (count == 0) return;
+    const ncclDataType_t t = nccl_type(dt);
+    group_start();
+    check_nccl(ncclSend(src, count, t, rank_, (ncclComm_t)comm_, stream), "ncclSend(self)");
+    check_nccl(ncclRecv(dst, count, t, rank_, (ncclComm_t)comm_, stream), "ncclRecv(self)");
+    group_end();
+}
+
 RcclComm::RcclComm(const std::string& unique_id, int rank, int world_size, int device)
     : Comm(rank, world_size), device_(device) {
     if (unique_id.size() != sizeof(ncclUniqueId))

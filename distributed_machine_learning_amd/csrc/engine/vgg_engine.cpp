@@ -119,6 +119,7 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
     // conv layers whose bit is set (bit i = layer i, 1 = all) are not launched and their gradients
     // stay stale, which shows what the main chain takes without them.
     if (const char* e = getenv("DML_EXPERIMENT_NO_WGRAD")) experiment_no_wgrad_ = atoi(e);
+    if (const char* e = getenv("DML_DEBUG_TAP")) debug_tap_layer_ = atoi(e);
     const ParamLayout lay = plan_parameters(widths, batch_norm, num_classes);
     for (const ParamLayout::Conv& l : lay.convs) {
         Conv c;
@@ -503,11 +504,31 @@ std::vector<long long> VggEngine::bn_save_offsets() const {
     return out;
 }
 
+void VggEngine::debug_tap(const void* src, size_t bytes, hipStream_t stream) {
+    constexpr size_t kRoom = 16u << 20;
+    if (!debug_tap_) check_hip(hipMalloc((void**)&debug_tap_, kRoom), "hipMalloc(debug tap)");
+    if (debug_tap_bytes_ + bytes > kRoom) throw std::logic_error("VggEngine: debug tap overflow");
+    check_hip(hipMemcpyAsync(debug_tap_ + debug_tap_bytes_, src, bytes, hipMemcpyDeviceToDevice, stream),
+              "hipMemcpyAsync(debug tap)");
+    debug_tap_bytes_ += bytes;
+    debug_tap_sections_.push_back(bytes);
+}
+
+std::string VggEngine::debug_tap_bytes() const {
+    std::string out(debug_tap_bytes_, '\0');
+    if (debug_tap_) {
+        check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(debug tap)");
+        check_hip(hipMemcpy(&out[0], debug_tap_, debug_tap_bytes_, hipMemcpyDeviceToHost), "hipMemcpy(debug tap)");
+    }
+    return out;
+}
+
 std::vector<std::vector<long long>> VggEngine::layer_table() const {
     std::vector<std::vector<long long>> out;
     for (const Conv& c : convs_)
         out.push_back({c.cin, c.cout, c.hw, c.pool_after ? 1 : 0, (long long)c.pre_off,
-                       (long long)c.out_off, (long long)c.pool_off});
+                       (long long)c.out_off, (long long)c.pool_off, (long long)c.gout_off,
+                       (long long)c.wd_off});
     return out;
 }
 
@@ -695,6 +716,14 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
         uint16_t* g = arena_ + c.gout_off;       // dL/d(conv output), ReLU mask applied
         // first layer under BatchNorm + pool: its weight-gradient kernel forms g on the fly
         const bool g_on_the_fly = i == 0 && c.pool_after;
+        const bool tap_bn = bn_ && debug_tap_layer_ > 0 && i == debug_tap_layer_ - 1;
+        if (tap_bn) {
+            debug_tap(arena_ + c.pre_off, (size_t)rows * c.cout * 2, stream);
+            debug_tap(params_ + c.gamma_off, (size_t)c.cout * 4, stream);
+            debug_tap(params_ + c.beta_off, (size_t)c.cout * 4, stream);
+            debug_tap(ws_ + c.save_off, (size_t)c.cout * 8, stream);
+            debug_tap(transit, (size_t)rows * c.cout * 2 / (c.pool_after ? 4 : 1), stream);
+        }
         if (bn_ && c.pool_after)
             bn_relu_pool_bwd(arena_ + c.pre_off, transit, g_on_the_fly ? nullptr : g,
                              params_ + c.gamma_off,
@@ -708,6 +737,11 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             bn_relu_bwd(arena_ + c.pre_off, transit, g, params_ + c.gamma_off, params_ + c.beta_off,
                         ws_ + c.save_off, ws_ + c.save_off + c.cout, grads_ + c.gamma_off,
                         grads_ + c.beta_off, ws_ + stats_off_, rows, c.cout, stream, pending, bn_sums);
+        if (tap_bn) {
+            debug_tap(g, (size_t)rows * c.cout * 2, stream);
+            debug_tap(grads_ + c.gamma_off, (size_t)c.cout * 4, stream);
+            debug_tap(grads_ + c.beta_off, (size_t)c.cout * 4, stream);
+        }
         if (g_on_the_fly && !bn_) {
             conv1_wgrad_relu_pool(x, arena_ + c.out_off, transit, grads_ + c.w_off,
                                   grads_ + c.b_off, batch, slab, stream);
@@ -773,6 +807,13 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
                               ? dgrad_force_plan_[i].data() : nullptr, nullptr,
                           defer_sum ? &pending : nullptr, want_sums ? &red : nullptr,
                           want_sums ? &bn_sums : nullptr, hand && by_value ? &raise : nullptr);
+            if (i == debug_tap_layer_) {
+                const size_t out_bytes = (size_t)batch * c.hw * c.hw * c.cin * 2;
+                debug_tap_sections_.clear();
+                debug_tap_bytes_ = 0;
+                if (9 * out_bytes * 2 <= slab_elems_ * sizeof(float)) debug_tap(slab, 9 * out_bytes * 2, stream);
+                debug_tap(arriving(i - 1), out_bytes, stream);
+            }
         }
         if (hand) {
             if (by_value)
@@ -974,11 +1015,14 @@ void bind_engine(py::module_& m) {
         .def_property_readonly("num_conv", &VggEngine::num_conv)
         .def_property_readonly("layer_table", &VggEngine::layer_table)
         .def_property_readonly("bn_save_offsets", &VggEngine::bn_save_offsets)
+        .def("debug_tap_bytes", [](const VggEngine& e) { return py::bytes(e.debug_tap_bytes()); })
+        .def_property_readonly("debug_tap_sections", &VggEngine::debug_tap_sections)
         .def_property("bn_steps", &VggEngine::bn_steps, &VggEngine::set_bn_steps)
         .def("bind", [](VggEngine& e, uintptr_t p, uintptr_t g, uintptr_t mo, uintptr_t bn,
                         uintptr_t arena, uintptr_t ws) {
             e.bind((float*)p, (float*)g, (float*)mo, (float*)bn, (uint16_t*)arena, (float*)ws);
         })
+        .def("set_value_hand_offs", &VggEngine::set_value_hand_offs)
         .def("set_wgrad_overlap", [](VggEngine& e, bool on, int group, uintptr_t compute_stream) {
             e.set_wgrad_overlap(on, group, (hipStream_t)compute_stream);
         }, py::arg("on"), py::arg("group") = 2, py::arg("compute_stream") = 0)

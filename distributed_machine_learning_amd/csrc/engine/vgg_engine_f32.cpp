@@ -544,6 +544,7 @@ void bind_engine_f32(py::module_& m) {
         }, py::keep_alive<1, 2>())
         .def("set_manual_sync", [](VggEngineF32& e, ManualSync* m) { e.set_manual_sync(m); },
              py::keep_alive<1, 2>())
+        .def("set_value_hand_offs", &VggEngineF32::set_value_hand_offs)
         .def("set_wgrad_overlap", [](VggEngineF32& e, bool on, uintptr_t compute_stream) {
             e.set_wgrad_overlap(on, (hipStream_t)compute_stream);
         }, py::arg("on"), py::arg("compute_stream") = 0)

@@ -138,6 +138,10 @@ class Comm {
 class RcclComm : public Comm {
   public:
     static std::string unique_id();     // 128 opaque bytes, created on rank 0
+    static int version();               // ncclGetVersion
+    // One grouped ncclSend + ncclRecv of this rank with ITSELF (dst := src through the transport):
+    // the point-to-point calls gather / scatter are built from, executable with a single rank.
+    void self_exchange(const void* src, void* dst, size_t count, DType dt, hipStream_t stream);
     RcclComm(const std::string& unique_id, int rank, int world_size, int device);
     ~RcclComm() override;
 
@@ -250,9 +254,10 @@ std::vector<BucketRange> plan_buckets(const std::vector<size_t>& sizes_bytes, si
 // ------------------------------------------------------------------- BucketReducer
 // Overlaps gradient all-reduce with the rest of backward.  Gradients live in one flat
 // fp32 buffer; a bucket is a contiguous element range of it.  `bucket_ready(b, compute)`
-// records an event on the compute stream, makes the communication stream wait on it and
-// enqueues the all-reduce of that slice in place; `wait_all(compute)` makes the compute
-// stream wait for every outstanding bucket (called right before the optimizer kernel).
+// orders the communication stream behind the compute stream's work so far (flag word or event
+// pair, see departure_mode) and enqueues the all-reduce of that slice in place;
+// `wait_all(compute)` makes the compute stream wait for every outstanding bucket (called right
+// before the optimizer kernel).
 // No host synchronisation, no staging copies.
 //
 // Module buffers (BatchNorm running statistics) follow rank 0 the way
@@ -281,6 +286,10 @@ class BucketReducer {
     hipStream_t comm_stream() const { return comm_stream_; }
     // "value": flag word + wait-value packet, "event": event pair
     const char* departure_mode() const { return by_value_ ? "value" : "event"; }
+    // Between steps, with both streams idle: switch the form of departure (the same schedule and
+    // arithmetic either way, so runs from one snapshot must agree bit for bit).
+    void set_departure_by_value(bool on);
+    bool can_depart_by_value() const { return can_wait_value_ != 0 && !serialize_; }
     // Send gradients as bf16: `wire` is a bf16 buffer as long as the flat gradient buffer (same
     // element offsets).  A bucket is rounded into it, summed there and widened back into the
     // fp32 gradients, all on the stream that runs its collective.  nullptr: fp32 on the wire.
@@ -319,6 +328,7 @@ class BucketReducer {
     unsigned* ready_flags_ = nullptr;
     unsigned step_seq_ = 0;
     bool by_value_ = false;
+    int can_wait_value_ = 0;                // hipDeviceAttributeCanUseStreamWaitValue
     bool done_by_value_ = false;            // how the most recent bucket reports completion
     std::vector<char> launched_;
     int last_ready_ = -1;

@@ -20,6 +20,8 @@
 //                               BatchNorm saved statistics, split-K slabs
 #pragma once
 
+#include <stdexcept>
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -88,6 +90,14 @@ class VggEngine {
     bool wgrad_overlap() const { return wgrad_overlap_; }
     // "value": flag word + wait-value packet, "event": event pair (see StreamSignal)
     const char* hand_off_mode() const { return value_hand_off_ ? "value" : "event"; }
+    // Between steps, with the device idle: hand-offs through flag words (true; needs the words
+    // allocated when the side stream was created) or through event pairs (false) - the same
+    // schedule either way, so two runs from one snapshot must agree bit for bit.
+    void set_value_hand_offs(bool on) {
+        if (on && !hand_off_flags_)
+            throw std::logic_error("engine: flag-word hand-offs are not available on this device");
+        value_hand_off_ = on;
+    }
     hipStream_t wgrad_stream() const { return wgrad_stream_; }
     // Overlap the parameter update of the deep layers with the first layers of the NEXT forward
     // (side-stream mode only).  optimizer_step() then updates and repacks the conv layers below
@@ -138,6 +148,8 @@ class VggEngine {
     int num_conv() const { return (int)convs_.size(); }
     // per conv layer: {cin, cout, hw, pool_after, pre_off, out_off, pool_off} (arena elements)
     std::vector<std::vector<long long>> layer_table() const;
+    std::string debug_tap_bytes() const;
+    std::vector<size_t> debug_tap_sections() const { return debug_tap_sections_; }     // host copy of the tap (device synchronised), see DML_DEBUG_TAP
     // workspace offset of each layer's saved [mean | rstd] (2 * cout floats), -1 without BatchNorm
     std::vector<long long> bn_save_offsets() const;
     ~VggEngine();
@@ -212,6 +224,13 @@ class VggEngine {
     std::vector<int> wgrad_queue_;          // layers whose gradient is ready, wgrad not yet launched
     bool tuned_wgrad_splits_ = true;        // use conv3x3_wgrad_tuned_splits where it has an entry
     int experiment_no_wgrad_ = 0;           // timing experiment (wrong gradients): see the constructor
+    // debugging tap (DML_DEBUG_TAP=<layer>): device copies of the split slabs and of the gradient
+    // that layer's backward-data pass produced, taken in stream order right behind it
+    int debug_tap_layer_ = -1;
+    char* debug_tap_ = nullptr;
+    size_t debug_tap_bytes_ = 0, debug_tap_slab_bytes_ = 0;
+    std::vector<size_t> debug_tap_sections_;
+    void debug_tap(const void* src, size_t bytes, hipStream_t stream);
     // tuning (DML_DGRAD_PLANS): backward-data plan {bm, bn, splits, pm, waves} per conv layer, bm 0 = default
     std::vector<std::array<int, 5>> dgrad_force_plan_;
     // forward of the 2x2 layers under BatchNorm: split-K finish + statistics + apply in one launch
@@ -274,6 +293,14 @@ class VggEngineF32 {
     void set_wgrad_overlap(bool on, hipStream_t compute_stream = nullptr);
     bool wgrad_overlap() const { return overlap_; }
     const char* hand_off_mode() const { return value_hand_off_ ? "value" : "event"; }
+    // Between steps, with the device idle: hand-offs through flag words (true; needs the words
+    // allocated when the side stream was created) or through event pairs (false) - the same
+    // schedule either way, so two runs from one snapshot must agree bit for bit.
+    void set_value_hand_offs(bool on) {
+        if (on && !hand_off_flags_)
+            throw std::logic_error("engine: flag-word hand-offs are not available on this device");
+        value_hand_off_ = on;
+    }
     hipStream_t wgrad_stream() const { return side_; }
     ~VggEngineF32();
 

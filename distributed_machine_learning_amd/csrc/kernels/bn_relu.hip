@@ -17,6 +17,8 @@
 #include <string>
 
 #include "dml_column_reduce.h"
+#include <vector>
+
 #include "dml_common.h"
 #include "dml_kernels.h"
 

@@ -26,12 +26,30 @@ __global__ void spin_kernel(long long ticks) {
 
 __global__ void empty_kernel() {}
 
+// What a stream that waits for the host looks like to the kernels around it: one lane per block
+// polling a flag word (system-scope loads), asleep in between, until the flag is raised or the
+// time is up.
+__global__ void poll_kernel(const unsigned* flag, long long ticks) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+        __builtin_amdgcn_s_sleep(64);
+        if (wall_clock64() - t0 > ticks) break;
+    }
+}
+
 void check(hipError_t e, const char* what) {
     if (e != hipSuccess)
         throw std::runtime_error(std::string("HIP ") + what + " failed: " + hipGetErrorString(e));
 }
 
 }  // namespace
+
+void launch_pollers(int blocks, long long ticks, const unsigned* flag, hipStream_t stream) {
+    if (blocks <= 0 || blocks > 4096 || ticks <= 0 || ticks > 1000000000LL)
+        throw std::invalid_argument("launch_pollers: bad block count or duration");
+    hipLaunchKernelGGL(poll_kernel, dim3(blocks), dim3(64), 0, stream, flag, ticks);
+}
 
 bool streams_run_concurrently(hipStream_t busy, hipStream_t candidate) {
     check(hipStreamSynchronize(busy), "hipStreamSynchronize");

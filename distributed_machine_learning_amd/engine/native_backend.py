@@ -223,9 +223,54 @@ class NativeBackend:
             return
         raise ValueError(cfg.sync)
 
+    # ------------------------------------------- cross-stream / cross-GPU hand-off forms
+    def handoff_forms(self) -> Dict[str, str]:
+        """How the step's hand-offs are expressed right now: ``engine`` = main stream -> weight-
+        gradient stream inside this GPU, ``buckets`` = gradient buckets -> communication stream
+        (whose collective lets peers read this GPU's memory).  "value": flag word + wait-value
+        packet, "event": event pair."""
+        out = {"engine": str(self.engine.hand_off_mode)}
+        if self.reducer is not None:
+            out["buckets"] = str(self.reducer.departure_mode)
+        return out
+
+    def set_handoff_forms(self, by_value: bool) -> None:
+        """Switch every hand-off to flag words (True) or event pairs (False).  The schedule and the
+        arithmetic are the same either way; only call it between steps, device idle."""
+        torch.cuda.synchronize(self.device)
+        if by_value:
+            try:
+                self.engine.set_value_hand_offs(True)
+            except Exception:       # noqa: BLE001 - a device without wait-value support keeps events
+                pass
+            if self.reducer is not None and self.reducer.can_depart_by_value:
+                self.reducer.set_departure_by_value(True)
+        else:
+            self.engine.set_value_hand_offs(False)
+            if self.reducer is not None:
+                self.reducer.set_departure_by_value(False)
+
+    def snapshot(self):
+        """Every piece of training state a step changes (see ``restore``)."""
+        return (self.params.clone(), self.momentum.clone(), self.bn_buffers.clone(),
+                int(self.engine.bn_steps))
+
+    @torch.no_grad()
+    def restore(self, snap) -> None:
+        torch.cuda.current_stream().synchronize()
+        self.params.copy_(snap[0])
+        self.momentum.copy_(snap[1])
+        self.bn_buffers.copy_(snap[2])
+        self.engine.bn_steps = snap[3]
+        if getattr(self, "reducer", None) is not None:
+            self.reducer.drop_pending_buffers()
+        self.engine.refresh_weights(self._stream())
+        torch.cuda.current_stream().synchronize()
+
     def sync_plan(self):
         """What the step synchronises, for logs and benchmark records."""
-        plan = {"mode": self.sync_name, "grad_scale": self._grad_scale}
+        plan = {"mode": self.sync_name, "grad_scale": self._grad_scale,
+                "engine_hand_off": str(self.engine.hand_off_mode)}
         if self.reducer is not None:
             plan["buckets_mb"] = [round(c * 4 / (1 << 20), 3) for _, c in self._bucket_slices]
             plan["inline_last_bucket"] = bool(self.reducer.inline_last)
@@ -401,19 +446,10 @@ class NativeBackend:
         more than one rank every rank must call it with the same ``steps``."""
         if steps <= 0:
             return
-        keep = (self.params.clone(), self.momentum.clone(), self.bn_buffers.clone(),
-                int(self.engine.bn_steps))
+        keep = self.snapshot()
         for i in range(steps):
             self.train_step(*batches[i % len(batches)])
-        torch.cuda.current_stream().synchronize()
-        self.params.copy_(keep[0])
-        self.momentum.copy_(keep[1])
-        self.bn_buffers.copy_(keep[2])
-        self.engine.bn_steps = keep[3]
-        if getattr(self, "reducer", None) is not None:
-            self.reducer.drop_pending_buffers()
-        self.engine.refresh_weights(self._stream())
-        torch.cuda.current_stream().synchronize()
+        self.restore(keep)
 
     def parameters_flat(self) -> torch.Tensor:
         return self.params

@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--inline-last-bucket", type=int, default=None)
     ap.add_argument("--serialize-streams", action="store_true")
     ap.add_argument("--arch", default="VGG11")
+    ap.add_argument("--no-broadcast-buffers", action="store_true")
+    ap.add_argument("--wgrad-overlap", type=int, default=1)
+    ap.add_argument("--state-hashes", action="store_true")
     ap.add_argument("--out", required=True)
     ns = ap.parse_args()
     cfg = TrainConfig(master_ip=ns.master_ip, rank=ns.rank, num_nodes=ns.num_nodes, sync=ns.sync,
@@ -50,7 +53,9 @@ def main():
                       grad_comm_dtype=ns.grad_comm_dtype,
                       inline_last_bucket=(None if ns.inline_last_bucket is None
                                           else bool(ns.inline_last_bucket)),
-                      serialize_streams=ns.serialize_streams)
+                      serialize_streams=ns.serialize_streams,
+                      broadcast_buffers=not ns.no_broadcast_buffers,
+                      wgrad_overlap=bool(ns.wgrad_overlap))
     torch.set_num_threads(2)
     if ns.device == "cuda":
         index = int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count()
@@ -75,6 +80,30 @@ def main():
         comm.guard_sync(60.0)
     sd = {k: v.float().cpu() for k, v in tr.backend.state_dict().items()}
     torch.save(sd, f"{ns.out}.rank{ns.rank}")
+    if ns.state_hashes:
+        # per-4096-element sums of the raw bits of every engine buffer: which region of which
+        # buffer two runs of one schedule disagree on
+        nb = tr.backend
+        torch.cuda.synchronize()
+
+        def chunks(t):
+            v = t.view(torch.int16 if t.element_size() == 2 else torch.int32).to(torch.int64)
+            pad = (-v.numel()) % 4096
+            v = torch.cat([v, v.new_zeros(pad)])
+            return v.view(-1, 4096).sum(1).cpu()
+
+        h = {"arena": chunks(nb.arena), "workspace": chunks(nb.workspace),
+             "grads": chunks(nb.grads), "table": torch.tensor(nb.engine.layer_table),
+             "save": torch.tensor(nb.engine.bn_save_offsets),
+             "full_arena": nb.arena.view(torch.int16).cpu(),
+             "full_workspace": nb.workspace.view(torch.int32).cpu(),
+             "full_grads": nb.grads.view(torch.int32).cpu()}
+        tap = nb.engine.debug_tap_bytes()
+        if tap:
+            import numpy as np
+            h["tap"] = torch.from_numpy(np.frombuffer(tap, dtype=np.int16).copy())
+            h["tap_sections"] = torch.tensor(list(nb.engine.debug_tap_sections))
+        torch.save(h, f"{ns.out}.hash{ns.rank}")
     if ns.report_overlap:
         import json
         split = tr.comm_split(train_loader, batches=2, steps=2)

@@ -105,7 +105,7 @@ def test_engine_layerwise_against_torch(batch_norm, B):
     # ------------------------------------------------------------------ forward
     saved = []
     inp = x
-    for L, (cin, cout, hw, pool, pre_off, out_off, pool_off) in enumerate(table):
+    for L, (cin, cout, hw, pool, pre_off, out_off, pool_off, _gout, _wd) in enumerate(table):
         w = _bf16(convs[L].weight.detach())
         y = F.conv2d(inp, w, convs[L].bias.detach(), padding=1)
         pre = None
@@ -155,7 +155,7 @@ def test_engine_layerwise_against_torch(batch_norm, B):
     expect("fc db", grads["fc1.bias"], dl.sum(0), 2e-3)
     g = _bf16(dl @ ref.fc1.weight.detach()).view(B, -1, 1, 1)
     for L in range(len(table) - 1, -1, -1):
-        cin, cout, hw, pool, pre_off, out_off, pool_off = table[L]
+        cin, cout, hw, pool, pre_off, out_off, pool_off = table[L][:7]
         inp_L, pre, out = saved[L]
         if pool:
             o = out.clone().requires_grad_(True)
@@ -435,6 +435,58 @@ def test_flag_word_hand_offs_match_event_hand_offs(batch_norm, dtype, monkeypatc
         assert torch.equal(other.momentum, base.momentum)
         other.close()
     base.close()
+
+
+def test_rccl_point_to_point_executes_with_one_rank():
+    """gather / scatter of the root-based mode are grouped ncclSend / ncclRecv
+    (/root/reference/part2/2a/main.py:101,114); with one rank those loops are empty.  The same
+    pair of calls addressed to the rank itself runs them once on a single GPU."""
+    from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
+    comm = RcclCommunicator("127.0.0.1:29641", 0, 1, 0, timeout_s=60)
+    C = comm.native
+    s = int(torch.cuda.current_stream().cuda_stream)
+    for dtype, code, n in ((torch.float32, 0, 1_179_648), (torch.bfloat16, 1, 4099), (torch.int64, 2, 7)):
+        src = (torch.arange(n, device=DEV) % 251).to(dtype)
+        dst = torch.zeros(n, dtype=dtype, device=DEV)
+        C.self_exchange(src.data_ptr(), dst.data_ptr(), n, code, s)
+        comm.guard_sync(60.0)
+        assert torch.equal(src, dst), dtype
+    from distributed_machine_learning_amd.ops import native
+    assert native.lib().rccl_version() > 20000
+    comm.destroy()
+
+
+def test_hand_off_forms_switch_at_run_time_and_agree():
+    """The self-check bench.py runs before a multi-rank measurement: the same steps from one
+    snapshot with flag-word hand-offs and with event pairs (engine and bucket reducer switched at
+    run time) give the same bits, and the backend comes back in the state and forms it had."""
+    from distributed_machine_learning_amd.config import TrainConfig
+    from distributed_machine_learning_amd.engine.native_backend import NativeBackend
+    from distributed_machine_learning_amd.parallel.comm import RcclCommunicator
+    from distributed_machine_learning_amd.utils.selfcheck import handoff_forms_agree
+    comm = RcclCommunicator("127.0.0.1:29642", 0, 1, 0, timeout_s=60)
+    torch.cuda.set_stream(torch.cuda.Stream(device=DEV))
+    try:
+        torch.manual_seed(99)
+        cfg = TrainConfig(batch_size=32, batch_norm=True, sync="ddp", dtype="bf16", backend="native",
+                          bucket_cap_mb=4.0, first_bucket_cap_mb=4.0, tail_bucket_cap_mb=1.0)
+        nb = NativeBackend(cfg, torch.device(DEV), comm)
+        nb.reducer.inline_last = False          # the multi-rank schedule
+        batches = [(_batch(32, seed=i)[1], _batch(32, seed=i)[2]) for i in range(3)]
+        before = nb.snapshot()
+        forms = nb.handoff_forms()
+        assert forms == {"engine": "value", "buckets": "value"}     # one rank: no remote readers
+        res = handoff_forms_agree(nb, comm, batches, steps=3)
+        assert res["ok"] is True
+        assert res["forms_compared"][0] == {"engine": "value", "buckets": "value"}
+        assert res["forms_compared"][1] == {"engine": "event", "buckets": "event"}
+        assert nb.handoff_forms() == forms
+        after = nb.snapshot()
+        assert torch.equal(before[0], after[0]) and torch.equal(before[2], after[2])
+        nb.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        comm.destroy()
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])

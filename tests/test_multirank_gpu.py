@@ -138,6 +138,18 @@ def test_ddp_bf16_wire_two_ranks(tmp_path):
             assert float((b16[0][k].double() - f32[0][k].double()).abs().max()) < 3e-2 * scale, k
 
 
+def test_ddp_bf16_wire_without_batchnorm_two_ranks(tmp_path):
+    """Without the BatchNorm staging tail a bucket's slice can have any length (the first one ends
+    with fc1.bias, 10 floats): the bf16 part is cut at a multiple of four elements and the rest
+    travels as fp32 in the same group."""
+    common = ["--sync", "ddp", "--batch-size", "8", "--iters", "3", "--bucket-cap-mb", "2"]
+    f32 = _run(tmp_path, "f32", 2, common)
+    b16 = _run(tmp_path, "b16", 2, common + ["--grad-comm-dtype", "bf16"])
+    assert _same(b16[0], b16[1])
+    assert not _same(b16[0], f32[0])
+    assert _rel(b16[0], f32[0]) < 2e-2
+
+
 def test_mismatched_replicas_fail_loudly(tmp_path):
     """Rank 1 builds a different network: the construction-time check must stop the job
     (what DistributedDataParallel's constructor does for the reference, part3/main.py:137)."""
@@ -184,6 +196,18 @@ def test_bench_self_launches_two_ranks_and_proves_it(mode):
         assert len(plan["buckets_mb"]) >= 3 and plan["inline_last_bucket"] is False
         assert plan["bucket_departure"] == "value"      # MI355X / ROCm 7 can wait for a value
     assert rec["extras_error"] is None
+    # the numerical self-checks of a multi-rank run: against rank 0 alone on the global batch in
+    # all three modes, and (bucketed mode) flag words against event pairs bit for bit
+    assert rec["self_checks_failed"] is None
+    dp = rec["dp_vs_single_rel_err"]
+    assert set(dp) == {"ddp", "gather_scatter", "all_reduce"} and all(v < 1e-4 for v in dp.values())
+    assert all(m["ranks_identical"] for m in rec["self_checks"]["data_parallel"]["modes"].values())
+    assert rec["extras"]["fp32_ms_per_step"] > 0 and rec["extras"]["transport"]["rccl_version"] > 20000
+    if mode == "part3":
+        assert rec["handoff_bitwise_ok"] is True
+        assert rec["extras"]["bf16_wire_ms_per_step"] > 0
+    else:
+        assert rec["handoff_bitwise_ok"] is None
     # what rank 0 moved per step, from the collectives issued inside the measured region: with
     # two ranks the root of gather/scatter receives and sends one model of gradients, a ring
     # all-reduce moves 2 (W-1)/W = 1 model each way (the report's per-node byte counts,
@@ -214,6 +238,18 @@ def test_bench_two_ranks_with_every_fallback_forced():
         assert rec["extras_error"] is None
         if mode == "part3":
             assert rec["config"]["sync_plan"]["bucket_departure"] == "event"
+
+
+def test_bench_one_rank_self_checks_on_rccl():
+    """The same checks forced on with one rank over RCCL itself (communicator, reducer, manual
+    sync and all record fields; the data-parallel run then IS the single-process run)."""
+    rec = _bench(["--steps", "5", "--warmup", "2", "--force-comm", "--self-checks", "on",
+                  "--inline-last-bucket", "0", "--windows", "1"])
+    assert rec["transport"] == "rccl" and rec["self_checks_failed"] is None
+    assert rec["handoff_bitwise_ok"] is True
+    assert all(v < 1e-6 for v in rec["dp_vs_single_rel_err"].values())
+    assert rec["config"]["sync_plan"]["bucket_departure"] == "value"
+    assert rec["comm_bytes_per_step"]["model"].startswith("ring")
 
 
 def test_bench_one_rank_rccl_record_fields():
