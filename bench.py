@@ -61,6 +61,10 @@ def parse(argv=None):
     bn.add_argument("--batch-norm", dest="batch_norm", action="store_true", default=None)
     bn.add_argument("--no-batch-norm", dest="batch_norm", action="store_false")
     ap.add_argument("--backend", choices=("native", "torch"), default="native")
+    ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda",
+                    help="cpu: the reference's own part1 set-up (one process, torch on the host, "
+                         "/root/reference/part1/main.py:15-16) - stock PyTorch only, fp32, for the "
+                         "baseline table's CPU row")
     ap.add_argument("--dtype", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU)")
     ap.add_argument("--bucket-cap-mb", type=float, default=4.5,
@@ -148,7 +152,8 @@ def self_launch(ns, argv) -> int:
         env = dict(os.environ)
         env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ns.gpus),
                    LOCAL_WORLD_SIZE=str(ns.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   DML_BENCH_SELF_LAUNCHED="1")
+                   DML_BENCH_SELF_LAUNCHED="1",
+                   DML_LAUNCH_ID=f"{os.getpid():x}{int(time.time() * 1e3) & 0xffffffff:x}")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), *argv],
                                       env=env))
@@ -221,20 +226,30 @@ def run_rank(ns) -> None:
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    if not torch.cuda.is_available():
+    on_cpu = ns.device == "cpu"
+    if on_cpu:
+        if ns.backend != "torch" or world != 1 or ns.force_comm:
+            raise SystemExit("--device cpu runs one process of the stock PyTorch backend "
+                             "(--backend torch, --gpus 1, no --force-comm)")
+        ns.dtype = "fp32"
+        ns.prime_steps = 0
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU")
-    n_dev = torch.cuda.device_count()
-    if ns.transport == "loopback":
+    n_dev = 1 if on_cpu else torch.cuda.device_count()
+    if on_cpu:
+        dev_index = 0
+    elif ns.transport == "loopback":
         dev_index = local_rank % n_dev
     elif local_rank >= n_dev:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPUs are visible "
                          "(RCCL needs one GPU per rank)")
     else:
         dev_index = local_rank
-    device = torch.device("cuda", dev_index)
-    torch.cuda.set_device(device)
+    device = torch.device("cpu") if on_cpu else torch.device("cuda", dev_index)
+    if not on_cpu:
+        torch.cuda.set_device(device)
     use_comm = world > 1 or ns.force_comm
-    if ns.compute_stream == "new" or (ns.compute_stream == "auto" and use_comm):
+    if not on_cpu and (ns.compute_stream == "new" or (ns.compute_stream == "auto" and use_comm)):
         torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
     from distributed_machine_learning_amd.data import synthetic_cifar
@@ -251,7 +266,7 @@ def run_rank(ns) -> None:
 
     cfg = TrainConfig(master_ip=master, rank=rank, num_nodes=world, sync=sync,
                       batch_size=ns.batch_size, batch_norm=batch_norm, dtype=ns.dtype,
-                      backend=ns.backend, device="cuda", use_graph=ns.graph,
+                      backend=ns.backend, device=ns.device, use_graph=ns.graph,
                       bucket_cap_mb=ns.bucket_cap_mb,
                       first_bucket_cap_mb=(ns.first_bucket_cap_mb if ns.first_bucket_cap_mb
                                            is not None else ns.bucket_cap_mb),
@@ -287,7 +302,8 @@ def run_rank(ns) -> None:
         # bounded: a lost rank raises here instead of hanging the survivors
         if comm is not None:
             comm.barrier(ns.comm_timeout)
-        torch.cuda.synchronize()
+        if not on_cpu:
+            torch.cuda.synchronize()
 
     host_loop = []      # per timed window: seconds until the LAST train_step call returned
 
@@ -469,7 +485,7 @@ def run_rank(ns) -> None:
                          "min_ms_per_step": round(win_ms[0], 4),
                          "median_ms_per_step": round(win_ms[len(win_ms) // 2], 4),
                          "max_ms_per_step": round(win_ms[-1], 4)} if win_ms else None),
-            "config": {"model": "VGG-11" + (" + BatchNorm" if batch_norm else ""),
+            "config": {"model": "VGG-11" + (" + BatchNorm" if batch_norm else ""), "device": ns.device,
                        "mode": ns.mode, "sync": sync, "global_batch": ns.batch_size * world,
                        "batch_per_gpu": ns.batch_size, "image": "3x32x32", "parallelism": par,
                        "optimizer": "SGD lr0.1 m0.9 wd1e-4 (fused)", "backend": backend.name,

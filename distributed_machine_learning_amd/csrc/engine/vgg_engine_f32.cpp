@@ -353,7 +353,11 @@ void VggEngineF32::backward(const float* x, const int64_t* target, int batch, hi
     sums_.n = 0;
     float* tb = arena_ + tb_off_;
     const bool by_value = overlap_ && value_hand_off_;
-    if (by_value && ++backward_seq_ == 0) {
+    // (a join word is raised up to twice per step and so runs ahead of the backward count: whichever
+    // counter is within a step's worth of 2^32 starts all the words over)
+    const unsigned top = 0xfffffff0u;
+    const bool joins_near_wrap = join_seq_[0] >= top || join_seq_[1] >= top || join_seq_[2] >= top;
+    if (by_value && (++backward_seq_ == 0 || joins_near_wrap)) {
         // the 32-bit sequence wrapped (2^32 backward passes): start the words over
         check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize(sequence wrap)");
         check_hip(hipMemset(hand_off_flags_, 0, (lay_.convs.size() + 3) * sizeof(unsigned)), "hipMemset(hand-off flags)");

@@ -31,9 +31,13 @@ def launch(script: str, script_args: List[str], nproc: int, master_addr: str = "
            master_port: int = 0, timeout_s: float = 0.0) -> int:
     port = master_port or free_port()
     procs = []
+    # one id per launch: the loopback transport names its shared-memory segment after it, so a
+    # segment a crashed earlier run left behind on the same port can never be mistaken for ours
+    launch_id = f"{os.getpid():x}{int(time.time() * 1e3) & 0xffffffff:x}"
     for rank in range(nproc):
         env = dict(os.environ)
         env["LOCAL_RANK"] = str(rank)
+        env["DML_LAUNCH_ID"] = launch_id
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         cmd = [sys.executable, "-u", script, *script_args,
                "--master-ip", f"{master_addr}:{port}", "--rank", str(rank),

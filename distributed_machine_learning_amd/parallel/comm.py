@@ -146,7 +146,10 @@ class RcclCommunicator(Communicator):
             self._comm = self._C.RcclComm(uid, rank, world_size, device_index)
         elif self.transport == "loopback":
             _, port = split_host_port(master_ip)
-            self._comm = self._C.LoopbackComm(str(port), rank, world_size, device_index,
+            # (the launcher's per-launch id keeps a crashed run's left-over segment on the same
+            # port out of reach; ranks started by hand share the port-only name)
+            name = str(port) + "_" + os.environ.get("DML_LAUNCH_ID", "")
+            self._comm = self._C.LoopbackComm(name.rstrip("_"), rank, world_size, device_index,
                                               float(timeout_s))
         else:
             raise ValueError(f"unknown transport {self.transport!r} (rccl | loopback)")

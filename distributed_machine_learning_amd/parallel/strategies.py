@@ -16,10 +16,12 @@ All strategies operate on views of the flat gradient buffer, so nothing is copie
 in or out.  ``reduce`` ("sum" | "mean") can override the per-mode default so the
 manual modes can be compared against a single-process run of the global batch.
 
-The classes here drive the stock-torch backend (autograd hooks mark gradients
-ready).  The native engine performs the same three protocols with its C++ reducer
-(csrc/comm/bucket_reducer.cpp) and calls ``GatherScatterSync``/``AllReduceSync``
-unchanged after its backward pass.
+The classes here drive the stock-torch backend only (autograd hooks mark gradients
+ready).  The native engine performs the same three protocols in C++ without passing
+through this module: the bucket reducer (csrc/comm/bucket_reducer.cpp) for part3 and
+``ManualSync`` (csrc/comm/manual_sync.cpp: grouped send / recv with an in-place root for
+part2a, one all-reduce per tensor for part2b), both enqueued by the engine itself between
+backward and the update.
 """
 from __future__ import annotations
 

@@ -192,6 +192,14 @@ def test_engine_layerwise_against_torch(batch_norm, B):
     assert not problems, "; ".join(problems)
 
 
+# Five SGD steps against the bf16-emulating torch model.  Measured on MI355X: without BatchNorm
+# loss 1.0e-6 / weights 5.3e-6 (the emulation reproduces the engine's roundings), with BatchNorm
+# 0.020 / 0.057 (batch statistics amplify the bf16 rounding of the activations they normalise,
+# and momentum carries it over the steps); the bounds are twice that, 20x without BatchNorm.
+LOSS_TOL = {False: 1e-4, True: 0.04}
+WEIGHT_TOL = {False: 1e-4, True: 0.12}
+
+
 @pytest.mark.parametrize("batch_norm", [False, True])
 def test_training_steps_track_torch(batch_norm):
     nb, ref = _mk(batch_norm)
@@ -205,17 +213,21 @@ def test_training_steps_track_torch(batch_norm):
         opt.step()
         losses_r.append(float(loss.detach()))
         losses_n.append(float(nb.train_step(x4, t).item()))
-    for a, b in zip(losses_n, losses_r):
-        assert abs(a - b) < 0.08 * max(1.0, abs(b)), (losses_n, losses_r)
+    worst_loss = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(losses_n, losses_r))
     sd = nb.state_dict()
+    worst_w = 0.0
     for name, p in ref.state_dict().items():
         if "num_batches" in name:
             assert int(sd[name]) == int(p)
             continue
-        # statistically equivalent, not bit-equal (see _emulated_forward): loose bound, and
-        # only on weight tensors (biases start at zero, a relative error means little there)
+        # statistically equivalent, not bit-equal (see _emulated_forward); only weight tensors
+        # (biases start at zero, a relative error means little there)
         if p.dim() >= 2:
-            assert _rel(sd[name], p) < 0.2, name
+            worst_w = max(worst_w, _rel(sd[name], p))
+    print(f"trajectory batch_norm={batch_norm}: worst loss error {worst_loss:.4g}, "
+          f"worst weight error {worst_w:.4g}")
+    assert worst_loss < LOSS_TOL[batch_norm], (losses_n, losses_r)
+    assert worst_w < WEIGHT_TOL[batch_norm], worst_w
 
 
 @pytest.mark.parametrize("arch", ["VGG13", "VGG16", "VGG19"])
