@@ -132,6 +132,10 @@ def parse(argv=None):
                     help="part3: how a gradient bucket is handed to the communication stream.  auto: "
                          "the reducer's own default, upgraded to flag words when the self-check has "
                          "just shown them bit-identical to event pairs on this communicator")
+    ap.add_argument("--rccl-max-channels", type=int, default=0,
+                    help="cap on RCCL's channels (NCCL_MAX_NCHANNELS, set before the communicator "
+                         "exists): fewer channels leave more compute units to backward while the "
+                         "buckets are in flight; 0 keeps the library's choice")
     ap.add_argument("--profile-ranges", action="store_true",
                     help="emit roctx ranges for the phases of the step (rocprofv3 --marker-trace)")
     return ap.parse_args(argv)
@@ -148,12 +152,14 @@ def self_launch(ns, argv) -> int:
     """Parent of a self-launched run.  Makes no GPU call and no exec of its own."""
     port = _free_port()
     procs = []
+    # (the loopback transport names its shared-memory segment after port and launch)
+    launch_id = f"{os.getpid():x}{int(time.time() * 1e3) & 0xffffffff:x}"
     for rank in range(ns.gpus):
         env = dict(os.environ)
         env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ns.gpus),
                    LOCAL_WORLD_SIZE=str(ns.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    DML_BENCH_SELF_LAUNCHED="1",
-                   DML_LAUNCH_ID=f"{os.getpid():x}{int(time.time() * 1e3) & 0xffffffff:x}")
+                   DML_LAUNCH_ID=launch_id)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), *argv],
                                       env=env))
@@ -260,6 +266,8 @@ def run_rank(ns) -> None:
     batch_norm = ns.batch_norm if ns.batch_norm is not None else (ns.mode == "part3")
     sync = MODE_SYNC[ns.mode] if use_comm else "none"
     comm = None
+    if ns.rccl_max_channels > 0:
+        os.environ["NCCL_MAX_NCHANNELS"] = str(ns.rccl_max_channels)
     if use_comm:
         comm = RcclCommunicator(master, rank, world, dev_index, timeout_s=ns.comm_timeout,
                                 transport=ns.transport)
@@ -486,6 +494,7 @@ def run_rank(ns) -> None:
                          "median_ms_per_step": round(win_ms[len(win_ms) // 2], 4),
                          "max_ms_per_step": round(win_ms[-1], 4)} if win_ms else None),
             "config": {"model": "VGG-11" + (" + BatchNorm" if batch_norm else ""), "device": ns.device,
+                       "rccl_max_channels": ns.rccl_max_channels or None,
                        "mode": ns.mode, "sync": sync, "global_batch": ns.batch_size * world,
                        "batch_per_gpu": ns.batch_size, "image": "3x32x32", "parallelism": par,
                        "optimizer": "SGD lr0.1 m0.9 wd1e-4 (fused)", "backend": backend.name,

@@ -216,7 +216,23 @@ void BucketReducer::reduce_slice(int b, hipStream_t stream) {
     if (n) comm_->all_reduce(wire_ + s.offset, n, DT_BF16, false, stream);
     if (tail) comm_->all_reduce(base + n, tail, DT_F32, false, stream);
     comm_->group_end();
-    if (n) cast_bf16_to_f32(wire_ + s.offset, base, n, stream);
+    if (n && !keep_on_wire_) cast_bf16_to_f32(wire_ + s.offset, base, n, stream);
+}
+
+void BucketReducer::set_keep_on_wire(bool on) {
+    if (on) {
+        if (!wire_) throw std::logic_error("BucketReducer: no bf16 payload to keep results on");
+        for (size_t b = 0; b < slices_.size(); ++b) {
+            size_t n = slices_[b].count;
+            const float* base = grads_ + slices_[b].offset;
+            if (buffers_count_ && buffers_staging_ >= base && buffers_staging_ < base + n)
+                n = (size_t)(buffers_staging_ - base);
+            if ((n & 3) || (slices_[b].offset & 3))
+                throw std::invalid_argument("BucketReducer: a slice that is not whole groups of four "
+                                            "cannot stay on the bf16 wire");
+        }
+    }
+    keep_on_wire_ = on;
 }
 
 void BucketReducer::wait_all(hipStream_t compute) {
@@ -436,6 +452,8 @@ void bind_comm(py::module_& m) {
         .def("set_bf16_payload", [](BucketReducer& r, uintptr_t wire) {
             r.set_bf16_payload((bf16_raw*)wire);
         })
+        .def("set_keep_on_wire", &BucketReducer::set_keep_on_wire)
+        .def_property_readonly("keeps_on_wire", &BucketReducer::keeps_on_wire)
         .def_property("inline_last", &BucketReducer::inline_last, &BucketReducer::set_inline_last)
         .def_property_readonly("departure_mode",
                                [](BucketReducer& r) { return std::string(r.departure_mode()); })

@@ -363,10 +363,21 @@ size_t VggEngine::layer_begin(int layer) const {
     return param_elems_;
 }
 
+void VggEngine::sgd_range(size_t begin, size_t n, float lr, float momentum, float weight_decay,
+                          float grad_scale, hipStream_t stream) {
+    // bf16 on the wire with the results left there: the update reads them in place
+    if (reducer_ && reducer_->keeps_on_wire())
+        sgd_momentum_bf16_grads(params_ + begin, reducer_->wire() + begin, mom_ + begin,
+                                arena_ + shadow_off_ + begin, n, lr, momentum, weight_decay,
+                                grad_scale, false, stream);
+    else
+        sgd_momentum(params_ + begin, grads_ + begin, mom_ + begin, arena_ + shadow_off_ + begin, n,
+                     lr, momentum, weight_decay, grad_scale, false, stream);
+}
+
 void VggEngine::sgd_slice(size_t begin, size_t end, hipStream_t stream) {
     if (end <= begin) return;
-    sgd_momentum(params_ + begin, grads_ + begin, mom_ + begin, arena_ + shadow_off_ + begin,
-                 end - begin, opt_.lr, opt_.mu, opt_.wd, opt_.gscale, false, stream);
+    sgd_range(begin, end - begin, opt_.lr, opt_.mu, opt_.wd, opt_.gscale, stream);
 }
 
 void VggEngine::join_wgrad_stream(hipStream_t stream) {
@@ -922,19 +933,16 @@ void VggEngine::optimizer_step(float lr, float momentum, float weight_decay, flo
         join_update(stream);
         const size_t cut = layer_begin(late_layer_);
         check_hip(hipEventRecord(grads_final_, stream), "hipEventRecord(grads final)");
-        sgd_momentum(params_, grads_, mom_, arena_ + shadow_off_, cut, lr, momentum, weight_decay,
-                     grad_scale, false, stream);
+        sgd_range(0, cut, lr, momentum, weight_decay, grad_scale, stream);
         repack_layers(1, late_layer_ < nconv ? late_layer_ : nconv, true, stream, bsrc, bdst, bn);
         check_hip(hipStreamWaitEvent(wgrad_stream_, grads_final_, 0), "hipStreamWaitEvent(grads final)");
-        sgd_momentum(params_ + cut, grads_ + cut, mom_ + cut, arena_ + shadow_off_ + cut,
-                     param_elems_ - cut, lr, momentum, weight_decay, grad_scale, false, wgrad_stream_);
+        sgd_range(cut, param_elems_ - cut, lr, momentum, weight_decay, grad_scale, wgrad_stream_);
         repack_layers(late_layer_ < 1 ? 1 : late_layer_, nconv, false, wgrad_stream_);
         check_hip(hipEventRecord(late_done_, wgrad_stream_), "hipEventRecord(late update)");
         late_pending_ = true;
         return;
     } else {
-        sgd_momentum(params_, grads_, mom_, arena_ + shadow_off_, param_elems_, lr, momentum,
-                     weight_decay, grad_scale, false, stream);
+        sgd_range(0, param_elems_, lr, momentum, weight_decay, grad_scale, stream);
     }
     repack_all(stream, bsrc, bdst, bn);
 }

@@ -294,6 +294,13 @@ class BucketReducer {
     // element offsets).  A bucket is rounded into it, summed there and widened back into the
     // fp32 gradients, all on the stream that runs its collective.  nullptr: fp32 on the wire.
     void set_bf16_payload(uint16_t* wire);
+    // The consumer (the engine's fused SGD) reads the reduced bf16 values from the wire buffer
+    // itself: no widening pass behind the collective.  The fp32 gradients then keep the LOCAL
+    // values.  Needs every slice's bf16 part to be whole groups of four (only BatchNorm staging
+    // floats may follow it).
+    void set_keep_on_wire(bool on);
+    bool keeps_on_wire() const { return wire_ && keep_on_wire_; }
+    const uint16_t* wire() const { return wire_; }
     // Whether a bucket marked `in_line` really runs on the compute stream (default) or goes
     // through the communication stream like every other bucket.
     void set_inline_last(bool on) { inline_last_ = on; }
@@ -321,6 +328,7 @@ class BucketReducer {
     bool average_, serialize_;
     bool inline_last_ = true;
     uint16_t* wire_ = nullptr;
+    bool keep_on_wire_ = false;
     hipStream_t comm_stream_ = nullptr;
     std::vector<hipEvent_t> ready_, done_;
     // Departures through flag words instead of the "ready" event pair (see bucket_ready): word b

@@ -180,6 +180,8 @@ class VggEngine {
     int wgrad_split_target() const { return bn_ ? 288 : 0; }
     size_t layer_begin(int layer) const;    // flat offset of the layer's first parameter slot
     void sgd_slice(size_t begin, size_t end, hipStream_t stream);
+    void sgd_range(size_t begin, size_t n, float lr, float momentum, float weight_decay,
+                   float grad_scale, hipStream_t stream);
     void repack_all(hipStream_t stream, const float* copy_src = nullptr, float* copy_dst = nullptr,
                     size_t copy_n = 0);
     // dgrad layouts of conv layers [lo, hi) (lo >= 1); with `conv1` also the first layer's padded

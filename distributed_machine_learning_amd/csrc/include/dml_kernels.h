@@ -305,6 +305,10 @@ void fc_train_grads(const bf16_raw* x, const float* ws, float* loss, int32_t* co
 // Also writes the bf16 shadow copy of p when `shadow` is non-null.
 void sgd_momentum(float* p, const float* g, float* m, bf16_raw* shadow, size_t n, float lr,
                   float mu, float wd, float grad_scale, bool first_step, hipStream_t stream);
+// the same update from bf16 gradients (a bf16 all-reduce's result, read in place)
+void sgd_momentum_bf16_grads(float* p, const bf16_raw* g, float* m, bf16_raw* shadow, size_t n,
+                             float lr, float mu, float wd, float grad_scale, bool first_step,
+                             hipStream_t stream);
 
 // out[i] = bf16(x[i])
 void cast_f32_to_bf16(const float* x, bf16_raw* out, size_t n, hipStream_t stream);

@@ -14,13 +14,24 @@ namespace dml {
 // ------------------------------------------------------------------------------- SGD
 // One launch updates the whole model: p, g, m are the flat fp32 buffers.  Memory-bound:
 // 16 B/lane loads and stores, grid capped at 2048 blocks with a grid-stride loop.
+// GW: the gradients are bf16 (the reduced values of a bf16 all-reduce, read where it left them).
+template <bool GW>
 __global__ __launch_bounds__(256) void sgd_momentum_kernel(
-    float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+    float4* __restrict__ p, const void* __restrict__ g_any, float4* __restrict__ m,
     uint2* __restrict__ shadow, size_t n4, float lr, float mu, float wd, float gscale, int first) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
-        float4 pv = p[i], gv = g[i], mv;
+        float4 pv = p[i], gv, mv;
+        if (GW) {
+            const uint2 w = ((const uint2*)g_any)[i];
+            gv.x = __builtin_bit_cast(float, w.x << 16);
+            gv.y = __builtin_bit_cast(float, w.x & 0xffff0000u);
+            gv.z = __builtin_bit_cast(float, w.y << 16);
+            gv.w = __builtin_bit_cast(float, w.y & 0xffff0000u);
+        } else {
+            gv = ((const float4*)g_any)[i];
+        }
         gv.x = gv.x * gscale + wd * pv.x;
         gv.y = gv.y * gscale + wd * pv.y;
         gv.z = gv.z * gscale + wd * pv.z;
@@ -49,19 +60,37 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(
     }
 }
 
-void sgd_momentum(float* p, const float* g, float* m, bf16_raw* shadow, size_t n, float lr,
-                  float mu, float wd, float grad_scale, bool first_step, hipStream_t stream) {
+namespace {
+void sgd_launch(float* p, const void* g, bool g_bf16, float* m, bf16_raw* shadow, size_t n, float lr,
+                float mu, float wd, float grad_scale, bool first_step, hipStream_t stream) {
     if (n % 4 != 0) throw std::invalid_argument("sgd_momentum: n must be a multiple of 4");
-    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m) & 15)
+    if ((((uintptr_t)p | (uintptr_t)m) & 15) || ((uintptr_t)g & (g_bf16 ? 7 : 15)))
         throw std::invalid_argument("sgd_momentum: buffers must be 16-byte aligned");
     if (n == 0) return;
     const size_t n4 = n / 4;
     const int block = 256;
     size_t blocks = (n4 + block - 1) / block;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)blocks), dim3(block), 0, stream,
-                       (float4*)p, (const float4*)g, (float4*)m, (uint2*)shadow, n4, lr, mu, wd,
-                       grad_scale, first_step ? 1 : 0);
+    if (g_bf16)
+        hipLaunchKernelGGL(sgd_momentum_kernel<true>, dim3((unsigned)blocks), dim3(block), 0, stream,
+                           (float4*)p, g, (float4*)m, (uint2*)shadow, n4, lr, mu, wd, grad_scale,
+                           first_step ? 1 : 0);
+    else
+        hipLaunchKernelGGL(sgd_momentum_kernel<false>, dim3((unsigned)blocks), dim3(block), 0, stream,
+                           (float4*)p, g, (float4*)m, (uint2*)shadow, n4, lr, mu, wd, grad_scale,
+                           first_step ? 1 : 0);
+}
+}  // namespace
+
+void sgd_momentum(float* p, const float* g, float* m, bf16_raw* shadow, size_t n, float lr,
+                  float mu, float wd, float grad_scale, bool first_step, hipStream_t stream) {
+    sgd_launch(p, g, false, m, shadow, n, lr, mu, wd, grad_scale, first_step, stream);
+}
+
+void sgd_momentum_bf16_grads(float* p, const bf16_raw* g, float* m, bf16_raw* shadow, size_t n,
+                             float lr, float mu, float wd, float grad_scale, bool first_step,
+                             hipStream_t stream) {
+    sgd_launch(p, g, true, m, shadow, n, lr, mu, wd, grad_scale, first_step, stream);
 }
 
 __global__ __launch_bounds__(256) void cast_f32_to_bf16_kernel(const float4* __restrict__ x,

@@ -191,6 +191,9 @@ class NativeBackend:
                 end = self.slots[hi - 1].offset + self.slots[hi - 1].numel
                 if stage and b == 0:        # the first bucket ends with the last parameter
                     end = e.param_elems + e.bn_elems
+                elif hi == len(self.slots):
+                    # up to the padded end of the flat buffer (zeros): whole groups of four
+                    end = e.param_elems
                 slices.append((start, end - start))
             self.buckets = buckets
             self._bucket_slices = slices
@@ -214,6 +217,10 @@ class NativeBackend:
                 # staging floats the first bucket's slice ends with (see BucketReducer)
                 self.reducer.set_buffer_sync(self.bn_buffers.data_ptr(),
                                              self.grads[e.param_elems:].data_ptr(), e.bn_elems)
+            if cfg.grad_comm_dtype == "bf16" and not self.fp32:
+                # the fused update reads the reduced bf16 values where the collective left them
+                # (no widening pass; ``grads`` keeps this rank's own gradients)
+                self.reducer.set_keep_on_wire(True)
             # what DistributedDataParallel's constructor does: everyone adopts rank 0's state
             if self.world > 1:
                 comm.broadcast(self._params, 0)
