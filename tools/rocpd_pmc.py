@@ -18,6 +18,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("db")
     ap.add_argument("--filter", default="conv")
+    ap.add_argument("--derive", action="store_true",
+                    help="ratios instead of raw counters (needs GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES, "
+                         "SQ_WAIT_ANY, SQ_WAVE_CYCLES, SQ_LDS_BANK_CONFLICT, SQ_BUSY_CU_CYCLES)")
     ns = ap.parse_args()
     con = sqlite3.connect(ns.db)
     cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
@@ -39,6 +42,25 @@ def main():
             if d not in seen and r[idx["start"]] and r[idx["end"]]:
                 seen.add(d)
                 table[key]["~wall_us"].append((float(r[idx["end"]]) - float(r[idx["start"]])) / 1e3)
+    if ns.derive:
+        def mean(v, c):
+            xs = v.get(c, [])
+            xs = xs[len(xs) // 2:] if len(xs) > 1 else xs
+            return sum(xs) / len(xs) if xs else float("nan")
+        print("# time = GRBM_GUI_ACTIVE / 8 XCDs / 2.4 GHz; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+              "(GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES; "
+              "LDS conflict = SQ_LDS_BANK_CONFLICT / SQ_BUSY_CU_CYCLES; wall = dispatch end - start")
+        print(f"{'kernel':66s} {'grid':>8s} {'time us':>8s} {'wall us':>8s} {'MFMA busy %':>11s} "
+              f"{'LDS conflict %':>14s} {'waiting %':>9s}")
+        for (name, grid), v in sorted(table.items()):
+            if ns.filter and ns.filter not in name:
+                continue
+            gui = mean(v, "GRBM_GUI_ACTIVE")
+            print(f"{name[:66]:66s} {grid:8d} {gui / 8 / 2400:8.1f} {mean(v, '~wall_us'):8.1f} "
+                  f"{100 * mean(v, 'SQ_VALU_MFMA_BUSY_CYCLES') / (gui / 8 * 1024):11.1f} "
+                  f"{100 * mean(v, 'SQ_LDS_BANK_CONFLICT') / mean(v, 'SQ_BUSY_CU_CYCLES'):14.1f} "
+                  f"{100 * mean(v, 'SQ_WAIT_ANY') / mean(v, 'SQ_WAVE_CYCLES'):9.1f}")
+        return
     counters = sorted({c for v in table.values() for c in v})
     print(f"{'kernel':60s} {'grid':>9s} " + " ".join(f"{c[-22:]:>22s}" for c in counters))
     for (name, grid), v in sorted(table.items()):
