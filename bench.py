@@ -136,6 +136,10 @@ def parse(argv=None):
                     help="cap on RCCL's channels (NCCL_MAX_NCHANNELS, set before the communicator "
                          "exists): fewer channels leave more compute units to backward while the "
                          "buckets are in flight; 0 keeps the library's choice")
+    ap.add_argument("--extras-deadline", type=float, default=300.0,
+                    help="seconds the checks and extra windows AFTER the measured region may take in "
+                         "total; past it rank 0 prints the record it has (extras_error says which "
+                         "phase was running) and every rank exits non-zero instead of hanging")
     ap.add_argument("--profile-ranges", action="store_true",
                     help="emit roctx ranges for the phases of the step (rocprofv3 --marker-trace)")
     return ap.parse_args(argv)
@@ -376,6 +380,8 @@ def run_rank(ns) -> None:
     # probe, self checks, communication split) must never cost the run its record: a failure in
     # one of them is reported in the record's `extras_error` instead.
     extras_error = None
+    phase = ["further windows"]
+    extra_windows = {}
     windows = []
     host_elapsed = float("nan")
     probe = 20                                  # host cost of enqueueing steps into an empty queue
@@ -383,81 +389,7 @@ def run_rank(ns) -> None:
     nranks_seen = comm.peer_count if comm is not None else 1
     in_sync = None
     overlap = None
-    try:
-        windows = [timed(ns.steps)[0] for _ in range(max(ns.windows, 0))]
-        t1 = time.perf_counter()
-        for i in range(probe):
-            backend.train_step(*batches[i % len(batches)])
-        host_elapsed = time.perf_counter() - t1
-        barrier()
-
-        # ---- cross-rank self checks
-        if comm is not None:
-            times = comm.all_gather_scalars(elapsed, torch.float32)
-            per_rank_ms = [round(float(t) / ns.steps * 1e3, 4) for t in times]
-            elapsed = float(times.max())                        # MAX over ranks
-            if windows:
-                w = torch.zeros(world, len(windows), device=device)
-                w[rank] = torch.tensor(windows, device=device)
-                comm.all_reduce(w)
-                comm.guard_sync(ns.comm_timeout)
-                windows = [float(v) for v in w.max(dim=0).values.cpu()]
-            # bit pattern checksum of the master weights: equal on every rank, or training diverged
-            flat = backend.parameters_flat()
-            checksum = int(flat.view(torch.int32).to(torch.int64).sum().item())
-            sums = comm.all_gather_scalars(checksum, torch.int64)
-            in_sync = bool((sums == sums[0]).all())
-
-        if comm is not None and (world > 1 or ns.report_overlap):
-            from distributed_machine_learning_amd.utils.overlap import measure_comm_split
-            overlap = measure_comm_split(backend, comm, batches, n=max(10, min(ns.steps, 50)))
-
-        # ---- correctness against an independent computation (see utils/selfcheck.py)
-        if comm is not None and checks_on and backend.name == "native":
-            from distributed_machine_learning_amd.utils import selfcheck
-            res = selfcheck.dp_and_manual_modes(cfg.replace(dtype=ns.dtype), comm, device,
-                                                backend.loader_layout)
-            self_checks["data_parallel"] = res
-            if not res["ok"]:
-                checks_failed.append("data_parallel")
-    except Exception as exc:                    # noqa: BLE001 - reported, then the run fails
-        extras_error = f"{type(exc).__name__}: {exc}"
-        print(f"[bench] rank {rank}: after the measured region: {extras_error}", file=sys.stderr)
-        if comm is not None and len(per_rank_ms) == 1 and world > 1:
-            # the MAX over ranks could not be taken: say so instead of passing off one rank's time
-            extras_error += " (ms_per_step is rank 0's own time, not the maximum over ranks)"
-
-    # ---- optional extra windows (never fatal): the reference's precision and bf16 on the wire
-    extra_windows = {}
-    if comm is not None and checks_on and backend.name == "native" and extras_error is None:
-        from distributed_machine_learning_amd.utils import selfcheck
-
-        def batches_for(layout):
-            t2 = BatchTransform(True, layout, SEED)
-            out = []
-            for i in range(2):
-                idx = torch.arange(ns.batch_size, device=device) * world + rank + i * ns.batch_size * world
-                imgs, labels = ds.take(idx)
-                out.append((t2(imgs, idx).contiguous(), labels.contiguous()))
-            return out
-
-        for name, over in (("fp32", {"dtype": "fp32"}),
-                           ("bf16_wire", {"dtype": "bf16", "grad_comm_dtype": "bf16"})):
-            if name == "bf16_wire" and (sync != "ddp" or ns.dtype != "bf16"):
-                continue
-            if name == "fp32" and ns.dtype == "fp32":
-                continue
-            try:
-                extra_windows[name + "_ms_per_step"] = selfcheck.timed_window(
-                    cfg, comm, device, batches_for, steps=20, warmup=5, **over)
-            except Exception as exc:            # noqa: BLE001
-                extra_windows[name + "_error"] = f"{type(exc).__name__}: {exc}"
-        try:
-            extra_windows["transport"] = selfcheck.transport_facts()
-        except Exception as exc:                # noqa: BLE001
-            extra_windows["transport_error"] = f"{type(exc).__name__}: {exc}"
-
-    if rank == 0:
+    def make_record(error):
         ms = elapsed / ns.steps * 1e3
         value = ns.batch_size * world * ns.steps / elapsed
         par = "single" if world == 1 else f"dp{world}"
@@ -471,7 +403,7 @@ def run_rank(ns) -> None:
             "dtype": ns.dtype, "data": "synthetic",
             "rccl_nranks": nranks_seen, "transport": ns.transport if comm is not None else "none",
             "per_rank_ms_per_step": per_rank_ms, "params_in_sync": in_sync,
-            "extras_error": extras_error,
+            "extras_error": error,
             # numerical self-checks on the live communicator (utils/selfcheck.py): None = not run
             "handoff_bitwise_ok": (self_checks.get("handoff_forms") or {}).get("ok"),
             "dp_vs_single_rel_err": ({m: v["rel_err_vs_single"] for m, v in
@@ -509,7 +441,110 @@ def run_rank(ns) -> None:
                        "final_loss": round(final_loss, 4), "overlap": overlap,
                        "baseline": f"reference {ns.mode}: {REFERENCE_IMAGES_PER_SEC[ns.mode]} "
                                    "images/s on its CPU cluster (group25.pdf)"}}
-        print(json.dumps(record), file=json_out, flush=True)
+        return record
+
+    import threading
+
+    def deadline_passed():
+        # a collective that never returns (a peer lost after the measured region) must not cost the
+        # run its record: print what there is, say where it stopped, leave without teardown
+        msg = (f"the work after the measured region did not finish within {ns.extras_deadline:.0f} s "
+               f"(phase: {phase[0]})")
+        print(f"[bench] rank {rank}: {msg}", file=sys.stderr, flush=True)
+        if rank == 0:
+            try:
+                print(json.dumps(make_record(msg)), file=json_out, flush=True)
+            except Exception as exc:            # noqa: BLE001
+                print(f"[bench] no record: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+            finally:
+                os._exit(4)
+        os._exit(4)
+
+    watchdog = threading.Timer(ns.extras_deadline, deadline_passed)
+    watchdog.daemon = True
+    watchdog.start()
+    try:
+        windows = [timed(ns.steps)[0] for _ in range(max(ns.windows, 0))]
+        phase[0] = "host enqueue probe"
+        t1 = time.perf_counter()
+        for i in range(probe):
+            backend.train_step(*batches[i % len(batches)])
+        host_elapsed = time.perf_counter() - t1
+        barrier()
+
+        # ---- cross-rank self checks
+        phase[0] = "maximum over ranks and parameter checksum"
+        if comm is not None:
+            times = comm.all_gather_scalars(elapsed, torch.float32)
+            per_rank_ms = [round(float(t) / ns.steps * 1e3, 4) for t in times]
+            elapsed = float(times.max())                        # MAX over ranks
+            if windows:
+                w = torch.zeros(world, len(windows), device=device)
+                w[rank] = torch.tensor(windows, device=device)
+                comm.all_reduce(w)
+                comm.guard_sync(ns.comm_timeout)
+                windows = [float(v) for v in w.max(dim=0).values.cpu()]
+            # bit pattern checksum of the master weights: equal on every rank, or training diverged
+            flat = backend.parameters_flat()
+            checksum = int(flat.view(torch.int32).to(torch.int64).sum().item())
+            sums = comm.all_gather_scalars(checksum, torch.int64)
+            in_sync = bool((sums == sums[0]).all())
+
+        phase[0] = "communication / compute split"
+        if comm is not None and (world > 1 or ns.report_overlap):
+            from distributed_machine_learning_amd.utils.overlap import measure_comm_split
+            overlap = measure_comm_split(backend, comm, batches, n=max(10, min(ns.steps, 50)))
+
+        # ---- correctness against an independent computation (see utils/selfcheck.py)
+        phase[0] = "data-parallel steps against the single-process global batch"
+        if comm is not None and checks_on and backend.name == "native":
+            from distributed_machine_learning_amd.utils import selfcheck
+            res = selfcheck.dp_and_manual_modes(cfg.replace(dtype=ns.dtype), comm, device,
+                                                backend.loader_layout)
+            self_checks["data_parallel"] = res
+            if not res["ok"]:
+                checks_failed.append("data_parallel")
+    except Exception as exc:                    # noqa: BLE001 - reported, then the run fails
+        extras_error = f"{type(exc).__name__}: {exc}"
+        print(f"[bench] rank {rank}: after the measured region: {extras_error}", file=sys.stderr)
+        if comm is not None and len(per_rank_ms) == 1 and world > 1:
+            # the MAX over ranks could not be taken: say so instead of passing off one rank's time
+            extras_error += " (ms_per_step is rank 0's own time, not the maximum over ranks)"
+
+    # ---- optional extra windows (never fatal): the reference's precision and bf16 on the wire
+    if comm is not None and checks_on and backend.name == "native" and extras_error is None:
+        from distributed_machine_learning_amd.utils import selfcheck
+
+        def batches_for(layout):
+            t2 = BatchTransform(True, layout, SEED)
+            out = []
+            for i in range(2):
+                idx = torch.arange(ns.batch_size, device=device) * world + rank + i * ns.batch_size * world
+                imgs, labels = ds.take(idx)
+                out.append((t2(imgs, idx).contiguous(), labels.contiguous()))
+            return out
+
+        for name, over in (("fp32", {"dtype": "fp32"}),
+                           ("bf16_wire", {"dtype": "bf16", "grad_comm_dtype": "bf16"})):
+            if name == "bf16_wire" and (sync != "ddp" or ns.dtype != "bf16"):
+                continue
+            if name == "fp32" and ns.dtype == "fp32":
+                continue
+            phase[0] = f"extra window {name}"
+            try:
+                extra_windows[name + "_ms_per_step"] = selfcheck.timed_window(
+                    cfg, comm, device, batches_for, steps=20, warmup=5, **over)
+            except Exception as exc:            # noqa: BLE001
+                extra_windows[name + "_error"] = f"{type(exc).__name__}: {exc}"
+        try:
+            extra_windows["transport"] = selfcheck.transport_facts()
+        except Exception as exc:                # noqa: BLE001
+            extra_windows["transport_error"] = f"{type(exc).__name__}: {exc}"
+
+
+    watchdog.cancel()
+    if rank == 0:
+        print(json.dumps(make_record(extras_error)), file=json_out, flush=True)
     if extras_error is not None:
         # The measured region itself completed on every rank (its closing barrier returned), so
         # the record stands and says what failed afterwards.  A failed collective may have left

@@ -143,3 +143,35 @@ def test_scaling_study_table():
     assert "0.150 ms" in lines[3] and "50 %" in lines[3] and "55.4" in lines[3] and "yes" in lines[3]
     assert "0.838" in lines[3]                            # the report's part3 time at four nodes
     assert lines[3].rstrip().endswith("1118x")            # 0.83813 s against 0.75 ms
+
+
+def _bench_cpu(*extra):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "part1", "--device",
+                           "cpu", "--backend", "torch", "--steps", "2", "--warmup", "1", "--batch-size",
+                           "16", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
+
+
+def test_bench_cpu_part1_prints_a_record():
+    """The reference's part1 is a CPU run of stock PyTorch (/root/reference/part1/main.py:15-16):
+    bench.py reproduces that set-up for the baseline table instead of refusing a host without GPU."""
+    import json
+    r = _bench_cpu("--windows", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["config"]["device"] == "cpu" and rec["config"]["backend"] == "torch"
+    assert rec["dtype"] == "fp32" and rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["extras_error"] is None and rec["windows"]["n"] == 1
+    # a CPU run with the native backend or a communicator is refused up front
+    assert _bench_cpu("--force-comm").returncode != 0
+
+
+def test_bench_keeps_its_record_when_the_extras_overrun_their_deadline():
+    """Work after the measured region (further windows, cross-rank checks) that does not return in
+    time must not cost the run its record: rank 0 prints it with the phase it was in, exit code 4."""
+    import json
+    r = _bench_cpu("--windows", "50", "--extras-deadline", "0.05")
+    assert r.returncode == 4, (r.returncode, r.stderr[-2000:])
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert rec["ms_per_step"] > 0 and "further windows" in rec["extras_error"]
