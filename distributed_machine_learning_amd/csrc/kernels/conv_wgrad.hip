@@ -369,7 +369,7 @@ int conv3x3_wgrad_tuned_splits(ConvShape s, bool batch_norm) {
     struct Entry { int hw, cin, cout, bn, plain; };
     static const Entry table[] = {
         {16, 64, 128, 40, 36}, {8, 128, 256, 10, 15}, {8, 256, 256, 10, 12},
-        {4, 256, 512, 2, 6},   {4, 512, 512, 3, 2},   {2, 512, 512, 1, 1},
+        {4, 256, 512, 3, 6},   {4, 512, 512, 3, 2},   {2, 512, 512, 1, 1},
     };
     for (const Entry& e : table)
         if (e.hw == s.hw && e.cin == s.cin && e.cout == s.cout) return batch_norm ? e.bn : e.plain;
