@@ -363,13 +363,15 @@ int conv3x3_wgrad_splits(ConvShape s, int split_target) {
 // two-stream backward the side stream's chain of weight-gradient kernels sets the pace, each of
 // them sharing the CUs with whatever the main chain runs at that moment, and the best split count
 // per layer is not a function of the block count alone: the tuned lists give 0.638 against
-// 0.653 ms/step with BatchNorm and 0.557 against 0.564 ms without.  0: no entry for this shape.
+// 0.653 ms/step with BatchNorm and 0.557 against 0.564 ms without.  Re-tuned with the tall conv tiles
+// on the main chain (their neighbours changed): 0.5520 -> 0.5508 ms with BatchNorm, 0.4975 -> 0.4855
+// without.  0: no entry for this shape.
 int conv3x3_wgrad_tuned_splits(ConvShape s, bool batch_norm) {
     if (s.batch != 256) return 0;
     struct Entry { int hw, cin, cout, bn, plain; };
     static const Entry table[] = {
-        {16, 64, 128, 40, 36}, {8, 128, 256, 10, 15}, {8, 256, 256, 10, 12},
-        {4, 256, 512, 3, 6},   {4, 512, 512, 3, 2},   {2, 512, 512, 1, 1},
+        {16, 64, 128, 40, 33}, {8, 128, 256, 10, 14}, {8, 256, 256, 10, 12},
+        {4, 256, 512, 3, 5},   {4, 512, 512, 3, 3},   {2, 512, 512, 1, 1},
     };
     for (const Entry& e : table)
         if (e.hw == s.hw && e.cin == s.cin && e.cout == s.cout) return batch_norm ? e.bn : e.plain;
