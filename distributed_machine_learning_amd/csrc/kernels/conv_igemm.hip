@@ -504,9 +504,12 @@ Plan choose_plan(int batch, int hw, int N, int cin, const int* force = nullptr) 
     if (tall_ok && hw <= 16 && hw >= 2) {
         if (blocks(256, 64) >= 256) return {256, 64, 1, false, 20 + v256};
         if (blocks(128, 64) >= 256) return {128, 64, 1, false, 20 + v128};
-        // half a block per CU: the channel chunks divided between two blocks per tile (fp32 slabs,
-        // summed by the consumer) - 256 -> 512 @ 4x4 backward-data
-        if (blocks(128, 64) * 2 >= 256 && cin >= 256) return {128, 64, 2, false, 20 + v128};
+        // Half a block per CU (256 -> 512 @ 4x4 backward-data): still one block per tile.  Dividing
+        // the channel chunks between two blocks per tile (fp32 slabs summed by the consumer, splits =
+        // 2, kept as a forced plan) is 2 us faster alone and 3-7 us slower inside the step
+        // (tools/tune_dgrad_plans.py): the unsplit block owns its pixel tile and leaves the previous
+        // layer's BatchNorm backward sums in its epilogue, which saves that layer's reduction pass.
+        if (blocks(128, 64) * 2 >= 256 && cin >= 256) return {128, 64, 1, false, 20 + v128};
     }
     // (two LDS stages and two blocks per CU beat three stages and one: a second block's main
     // loop covers the first one's prologue and epilogue, which are a third of a block's life at

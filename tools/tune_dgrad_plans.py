@@ -12,7 +12,10 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 ARGS = sys.argv[1:]
 CANDS = ["128:128:1:0:8", "128:128:1:0:9", "128:128:1:0:10", "128:128:3:-1:10", "128:128:1:0:4", "128:64:1:0:4", "64:64:1:0:4",
          "64:64:1:0:16", "128:64:1:0:16", "128:128:1:0:16", "128:128:3:-1:9", "128:128:3:-1:8",
-         "64:64:3:-1:4", "64:64:9:-1:4", "128:64:3:-1:4"]
+         "64:64:3:-1:4", "64:64:9:-1:4", "128:64:3:-1:4",
+         # tall patch-resident tiles (waves = 20 + variant, see conv_patch.hip)
+         "256:64:1:0:20", "256:64:1:0:21", "128:64:1:0:20", "128:64:1:0:21", "128:64:1:0:25",
+         "128:64:2:0:20"]
 
 
 def run(plans):
