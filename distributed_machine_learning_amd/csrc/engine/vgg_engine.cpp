@@ -198,8 +198,8 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         size_t need = (size_t)conv1_fprop_stats_rows(max_batch_) * 2 * convs_[0].cout;
         for (size_t i = 1; i < convs_.size(); ++i) {
             const Conv& c = convs_[i];
-            const size_t n = (size_t)conv3x3_igemm_stats_rows({max_batch_, c.hw, c.cin, c.cout}) *
-                             2 * c.cout;
+            // (one row per 64 pixels is the most any plan writes, forced ones included)
+            const size_t n = ((size_t)max_batch_ * c.hw * c.hw + 63) / 64 * 2 * c.cout;
             need = n > need ? n : need;
             // backward: the dgrad of this layer may leave the previous layer's BatchNorm sums,
             // one row per pixel tile of at least 64 rows
@@ -237,6 +237,19 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
             int k = 0;
             while (*q && *q != ',') {
                 if (k < 5) dgrad_force_plan_[i][k++] = atoi(q);
+                while (*q && *q != ':' && *q != ',') ++q;
+                if (*q == ':') ++q;
+            }
+            if (*q == ',') ++q;
+        }
+    }
+    fwd_force_plan_.assign(convs_.size(), std::array<int, 5>{0, 0, 0, -1, 0});
+    if (const char* e = getenv("DML_FWD_PLANS")) {     // tuning: same format, forward convolutions
+        size_t i = 1;
+        for (const char* q = e; *q && i < convs_.size(); ++i) {
+            int k = 0;
+            while (*q && *q != ',') {
+                if (k < 5) fwd_force_plan_[i][k++] = atoi(q);
                 while (*q && *q != ':' && *q != ',') ++q;
                 if (*q == ':') ++q;
             }
@@ -617,9 +630,10 @@ void VggEngine::forward(const uint16_t* x, int batch, bool training, hipStream_t
             part.rows = conv1_fprop_stats_rows(batch);
         } else {
             ConvShape s = {batch, c.hw, c.cin, c.cout};
+            const int* force = fwd_force_plan_[i][0] > 0 ? fwd_force_plan_[i].data() : nullptr;
             conv3x3_igemm(in, arena_ + shadow_off_ + c.w_off, dst, params_ + c.b_off, nullptr, slab,
-                          slab_elems_, s, bn_ ? EPI_BIAS : EPI_BIAS_RELU, stream, nullptr, cstats);
-            if (cstats) part.rows = conv3x3_igemm_stats_rows(s);
+                          slab_elems_, s, bn_ ? EPI_BIAS : EPI_BIAS_RELU, stream, force, cstats);
+            if (cstats) part.rows = conv3x3_igemm_stats_rows(s, force);
         }
         if (cstats) {
             part.data = cstats;

@@ -235,6 +235,7 @@ class VggEngine {
     void debug_tap(const void* src, size_t bytes, hipStream_t stream);
     // tuning (DML_DGRAD_PLANS): backward-data plan {bm, bn, splits, pm, waves} per conv layer, bm 0 = default
     std::vector<std::array<int, 5>> dgrad_force_plan_;
+    std::vector<std::array<int, 5>> fwd_force_plan_;      // DML_FWD_PLANS (tuning): forward plans, same format
     // forward of the 2x2 layers under BatchNorm: split-K finish + statistics + apply in one launch
     // (DML_FUSED_FINISH_BN=1; measured equal to the two launches it replaces, so off by default)
     bool fused_finish_bn_ = false;

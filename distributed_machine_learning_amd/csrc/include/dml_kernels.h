@@ -99,7 +99,7 @@ size_t conv3x3_igemm_workspace_elems(ConvShape s);
 // of squares of the BIAS-FREE output: stats[row][0][n], stats[row][1][n] for
 // conv3x3_igemm_stats_rows(s) rows - the BatchNorm statistics without another pass over y
 // (see BnPartials).
-int conv3x3_igemm_stats_rows(ConvShape s);
+int conv3x3_igemm_stats_rows(ConvShape s, const int* force_plan = nullptr);
 
 
 // First layer: x is [B,32,32,4] bf16 (3 channels + zero pad), w1 is [64][64] bf16 with

@@ -875,10 +875,10 @@ size_t conv3x3_igemm_workspace_elems(ConvShape s) {
     return pl.splits > 1 ? (size_t)9 * M * s.cout : 0;
 }
 
-int conv3x3_igemm_stats_rows(ConvShape s) {
+int conv3x3_igemm_stats_rows(ConvShape s, const int* force_plan) {
     check_shape(s, "conv3x3_igemm_stats_rows");
     const int M = s.batch * s.hw * s.hw;
-    const Plan pl = choose_plan(s.batch, s.hw, s.cout, s.cin);
+    const Plan pl = choose_plan(s.batch, s.hw, s.cout, s.cin, force_plan);
     if (pl.splits > 1) return finish_stats_plan(M, s.cout).blocks;
     return pl.pm ? s.hw * s.hw * ((s.batch + pl.bm - 1) / pl.bm) : (M + pl.bm - 1) / pl.bm;
 }
@@ -908,9 +908,8 @@ void conv3x3_igemm(const bf16_raw* x, const bf16_raw* w, bf16_raw* y, const floa
     a.bn_pooled = 1;
     a.signal = signal ? signal->flag : nullptr;
     a.signal_value = signal ? signal->value : 0u;
-    if (stats && (epi != EPI_BIAS || force_plan))
-        throw std::invalid_argument("conv3x3_igemm: statistics come with the default plan and "
-                                    "the bias-only epilogue");
+    if (stats && epi != EPI_BIAS)
+        throw std::invalid_argument("conv3x3_igemm: statistics come with the bias-only epilogue");
     a.M = s.batch * s.hw * s.hw; a.N = s.cout; a.C = s.cin;
     a.hw = s.hw; a.log_hw = ilog2(s.hw); a.log_chunks = ilog2(s.cin / 64);
     a.batch = s.batch; a.img_blocks = 0;

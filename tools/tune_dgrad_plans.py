@@ -2,6 +2,7 @@
 (DML_DGRAD_PLANS), one bench.py run per candidate; a candidate the launcher refuses is skipped.
 
     python tools/tune_dgrad_plans.py [bench args...]
+    KNOB=DML_FWD_PLANS python tools/tune_dgrad_plans.py          # the forward convolutions instead
 """
 import json
 import os
@@ -19,7 +20,8 @@ CANDS = ["128:128:1:0:8", "128:128:1:0:9", "128:128:1:0:10", "128:128:3:-1:10", 
 
 
 def run(plans):
-    env = dict(os.environ, DML_DGRAD_PLANS=",".join(plans))
+    env = dict(os.environ)
+    env[os.environ.get("KNOB", "DML_DGRAD_PLANS")] = ",".join(plans)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup",
                           "30", "--windows", "3"] + ARGS, capture_output=True, text=True, env=env,
                          timeout=200)
