@@ -48,22 +48,38 @@ def handoff_forms_agree(backend, comm, batches: Sequence[Tuple[torch.Tensor, tor
     was = backend.handoff_forms()
     snap = backend.snapshot()
     finals = []
-    for by_value in (True, False):
+    # (the event form twice: a transport that does not reproduce its OWN results bit for bit - a
+    # collective whose reduction order depends on timing - makes the comparison meaningless)
+    for by_value in (True, False, False):
         backend.set_handoff_forms(by_value)
         for i in range(steps):
             backend.train_step(*batches[i % len(batches)])
         torch.cuda.synchronize(backend.device)
         finals.append((backend.params.clone(), backend.bn_buffers.clone(), backend.handoff_forms()))
         backend.restore(snap)
-    same = bool(torch.equal(finals[0][0].view(torch.int32), finals[1][0].view(torch.int32)) and
-                torch.equal(finals[0][1].view(torch.int32), finals[1][1].view(torch.int32)))
+
+    def same_bits(a, b):
+        return bool(torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and
+                    torch.equal(a[1].view(torch.int32), b[1].view(torch.int32)))
+
+    same = same_bits(finals[0], finals[1])
+    repeatable = same_bits(finals[1], finals[2])
     moved = not torch.equal(finals[0][0], snap[0])          # (the steps did change something)
     torch.cuda.synchronize(backend.device)
     backend.engine.set_value_hand_offs(was["engine"] == "value")
     if backend.reducer is not None:
         backend.reducer.set_departure_by_value(was["buckets"] == "value")
-    ok = _all_agree(comm, same and moved, backend.device)
-    return {"ok": ok, "steps": steps, "forms_compared": [finals[0][2], finals[1][2]]}
+    repeatable_everywhere = _all_agree(comm, repeatable, backend.device)
+    agree_everywhere = _all_agree(comm, same and moved, backend.device)
+    out = {"steps": steps, "forms_compared": [finals[0][2], finals[1][2]],
+           "event_form_repeats_bitwise": repeatable_everywhere}
+    if not repeatable_everywhere:
+        out["ok"] = None
+        out["inconclusive"] = ("two runs of the event form differ: the transport does not reproduce its "
+                               "own results bit for bit, so the forms cannot be compared this way")
+    else:
+        out["ok"] = agree_everywhere
+    return out
 
 
 def _rel_err(a: torch.Tensor, b: torch.Tensor, slots) -> float:
