@@ -136,6 +136,12 @@ def parse(argv=None):
                     help="cap on RCCL's channels (NCCL_MAX_NCHANNELS, set before the communicator "
                          "exists): fewer channels leave more compute units to backward while the "
                          "buckets are in flight; 0 keeps the library's choice")
+    ap.add_argument("--plan-policy", choices=("auto", "tall", "streaming"), default="auto",
+                    help="convolution tile plans of the native bf16 engine: the tall patch-resident "
+                         "tiles (one block per CU, nearly all of its LDS) or the streaming tiles only. "
+                         "auto: tall on one GPU; with more than one rank both are timed on the live job "
+                         "before the measured region (a communication library's resident blocks can "
+                         "push a one-block-per-CU grid into a second round) and the faster one runs")
     ap.add_argument("--extras-deadline", type=float, default=300.0,
                     help="seconds the checks and extra windows AFTER the measured region may take in "
                          "total; past it rank 0 prints the record it has (extras_error says which "
@@ -366,6 +372,30 @@ def run_rank(ns) -> None:
             checks_failed.append("handoff_forms")
         barrier()
 
+    # ---- convolution plan policy (outside the timed region)
+    plan_policy = None
+    if backend.name == "native" and ns.dtype == "bf16":
+        from distributed_machine_learning_amd.ops import native as _native
+        _C = _native.lib()
+        if ns.plan_policy != "auto":
+            _C.set_conv_tall_tiles(ns.plan_policy == "tall")
+            plan_policy = {"chosen": ns.plan_policy, "how": "flag"}
+        elif world > 1 and comm is not None:
+            tried = {}
+            for name in ("tall", "streaming"):
+                _C.set_conv_tall_tiles(name == "tall")
+                for i in range(10):
+                    backend.train_step(*batches[i % len(batches)])
+                t_pol, _ = timed(40)
+                host_loop.pop()
+                times = comm.all_gather_scalars(t_pol, torch.float32)
+                tried[name] = round(float(times.max()) / 40 * 1e3, 4)
+            chosen = min(tried, key=tried.get)
+            _C.set_conv_tall_tiles(chosen == "tall")
+            plan_policy = {"chosen": chosen, "how": "timed on this job", "ms_per_step": tried}
+        else:
+            plan_policy = {"chosen": "tall" if _C.conv_tall_tiles() else "streaming", "how": "default"}
+
     if ns.prime_steps > 0 and hasattr(backend, "prime"):
         backend.prime(batches, ns.prime_steps)
         barrier()
@@ -431,6 +461,7 @@ def run_rank(ns) -> None:
                          "max_ms_per_step": round(win_ms[-1], 4)} if win_ms else None),
             "config": {"model": "VGG-11" + (" + BatchNorm" if batch_norm else ""), "device": ns.device,
                        "rccl_max_channels": ns.rccl_max_channels or None,
+                       "plan_policy": plan_policy,
                        "mode": ns.mode, "sync": sync, "global_batch": ns.batch_size * world,
                        "batch_per_gpu": ns.batch_size, "image": "3x32x32", "parallelism": par,
                        "optimizer": "SGD lr0.1 m0.9 wd1e-4 (fused)", "backend": backend.name,

@@ -257,11 +257,11 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         }
     }
     if (const char* e = getenv("DML_FUSED_FINISH_BN")) fused_finish_bn_ = atoi(e) != 0;
-    const char* tall_env = getenv("DML_TALL_TILES");
-    const bool tall_tiles = !(tall_env && tall_env[0] == '0');
     // (with the tall patch-resident tiles every backward-data pass of the flagship shapes owns its
-    // pixel tiles already; the override below belongs to the older plans)
-    if (!getenv("DML_DGRAD_PLANS") && bn_ && max_batch_ == 256 && !tall_tiles) {
+    // pixel tiles already; the override below belongs to the streaming plan policy and is looked up
+    // per call, since the policy can change between steps)
+    streaming_dgrad_plan_.assign(convs_.size(), std::array<int, 5>{0, 0, 0, -1, 0});
+    if (!getenv("DML_DGRAD_PLANS") && bn_ && max_batch_ == 256) {
         // Tuned inside the step (tools/tune_dgrad_plans.py, tools/ab_dgrad_l4.sh): the backward-data
         // pass of a 256 -> 512 layer on 4x4 maps runs 2.5 us per step faster on the 64 x 64
         // patch-resident kernel than on the default tap-split plan - a block that owns its pixel
@@ -269,8 +269,7 @@ VggEngine::VggEngine(const std::vector<int>& widths, int max_batch, bool batch_n
         // layer's stand-alone reduction pass.
         for (size_t i = 1; i < convs_.size(); ++i)
             if (convs_[i].hw == 4 && convs_[i].cin == 256 && convs_[i].cout == 512)
-                dgrad_force_plan_[i] = {64, 64, 1, 0, 16};
-        dgrad_plan_batch_ = 256;        // (a tuned default, not a forced plan: full batches only)
+                streaming_dgrad_plan_[i] = {64, 64, 1, 0, 16};
     }
     for (size_t i = 0; i < convs_.size(); ++i) {
         Conv& c = convs_[i];
@@ -828,8 +827,9 @@ void VggEngine::backward(const uint16_t* x, const int64_t* target, int batch, hi
             conv3x3_igemm(g, arena_ + c.wd_off, arriving(i - 1), nullptr,
                           fold_relu ? arena_ + prev.out_off : nullptr, slab, slab_elems_, d,
                           fold_relu ? EPI_MASK : EPI_NONE, stream,
-                          dgrad_force_plan_[i][0] > 0 && (!dgrad_plan_batch_ || batch == dgrad_plan_batch_)
-                              ? dgrad_force_plan_[i].data() : nullptr, nullptr,
+                          dgrad_force_plan_[i][0] > 0 ? dgrad_force_plan_[i].data()
+                          : (!conv_tall_tiles() && batch == 256 && streaming_dgrad_plan_[i][0] > 0)
+                              ? streaming_dgrad_plan_[i].data() : nullptr, nullptr,
                           defer_sum ? &pending : nullptr, want_sums ? &red : nullptr,
                           want_sums ? &bn_sums : nullptr, hand && by_value ? &raise : nullptr);
             if (i == debug_tap_layer_) {

@@ -160,10 +160,11 @@ class RcclComm : public Comm {
     void wait_stream(hipStream_t stream, double timeout_s) override;
     void destroy() override;
     void* raw() const { return comm_; }
+    int device() const { return device_; }
 
   private:
     void* comm_ = nullptr;      // ncclComm_t
-    int device_;
+    int device_;                // the GPU the communicator was created on
     int group_depth_ = 0;
     // root-side self copies of gather / scatter calls made inside an open group: issued when
     // the group closes, so they never interleave with the grouped transfers

@@ -230,16 +230,16 @@ class VggEngine {
     // that layer's backward-data pass produced, taken in stream order right behind it
     int debug_tap_layer_ = -1;
     char* debug_tap_ = nullptr;
-    size_t debug_tap_bytes_ = 0, debug_tap_slab_bytes_ = 0;
+    size_t debug_tap_bytes_ = 0;
     std::vector<size_t> debug_tap_sections_;
     void debug_tap(const void* src, size_t bytes, hipStream_t stream);
     // tuning (DML_DGRAD_PLANS): backward-data plan {bm, bn, splits, pm, waves} per conv layer, bm 0 = default
     std::vector<std::array<int, 5>> dgrad_force_plan_;
+    std::vector<std::array<int, 5>> streaming_dgrad_plan_;    // tuned defaults of the streaming plan policy
     std::vector<std::array<int, 5>> fwd_force_plan_;      // DML_FWD_PLANS (tuning): forward plans, same format
     // forward of the 2x2 layers under BatchNorm: split-K finish + statistics + apply in one launch
     // (DML_FUSED_FINISH_BN=1; measured equal to the two launches it replaces, so off by default)
     bool fused_finish_bn_ = false;
-    int dgrad_plan_batch_ = 0;              // > 0: the plans above are tuned defaults for this batch size only
     std::vector<int> wgrad_force_splits_;   // tuning (DML_WGRAD_SPLITS): pixel splits per conv layer, 0 = planned
     // tuning (DML_WGRAD_RESIDENT): "bco:stages" per conv layer to run the tap-resident kernel there
     // (with the layer's DML_WGRAD_SPLITS entry as its split count), "0" for the per-tap kernel

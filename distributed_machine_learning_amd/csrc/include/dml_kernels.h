@@ -100,6 +100,10 @@ size_t conv3x3_igemm_workspace_elems(ConvShape s);
 // conv3x3_igemm_stats_rows(s) rows - the BatchNorm statistics without another pass over y
 // (see BnPartials).
 int conv3x3_igemm_stats_rows(ConvShape s, const int* force_plan = nullptr);
+// plan policy of the bf16 convolutions: tall patch-resident tiles where they cover the chip
+// (default), or streaming tiles only; switchable between steps
+bool conv_tall_tiles();
+void set_conv_tall_tiles(bool on);
 
 
 // First layer: x is [B,32,32,4] bf16 (3 channels + zero pad), w1 is [64][64] bf16 with

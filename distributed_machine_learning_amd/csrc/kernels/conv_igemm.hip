@@ -37,6 +37,7 @@
 //     no atomics).
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <stdexcept>
 #include <string>
 
@@ -457,6 +458,25 @@ ColReducePlan finish_stats_plan(int M, int N) {
     return {blocks, rpb};
 }
 
+// Plan policy: the tall patch-resident tiles (default; DML_TALL_TILES=0 starts without them), or the
+// streaming tiles only.  A run-time switch because the better one depends on what else occupies the
+// compute units: a tall tile wants a CU's LDS almost to itself, so a communication library's
+// persistent blocks can push a 256-block grid into a second round (bench.py measures both policies on
+// the live job when there is more than one rank).
+std::atomic<int> g_tall_tiles{-1};
+}  // namespace igemm
+bool conv_tall_tiles() {
+    int v = igemm::g_tall_tiles.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("DML_TALL_TILES");
+        v = !(e && e[0] == '0');
+        igemm::g_tall_tiles.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+void set_conv_tall_tiles(bool on) { igemm::g_tall_tiles.store(on ? 1 : 0, std::memory_order_relaxed); }
+namespace igemm {
+
 struct Plan {
     int bm, bn, splits;
     bool pm;
@@ -490,10 +510,7 @@ Plan choose_plan(int batch, int hw, int N, int cin, const int* force = nullptr) 
     // new): 64->128@16 15.0 -> 15.3 / dgrad 18.5 -> 11.3, 128->256@8 14.9 -> 12.0 / 16.6 -> 11.7,
     // 256->256@8 24.4 -> 20.0 / 25.7 -> 16.9, 256->512@4 17.1 -> 11.5 / 22.0 -> 16.6,
     // 512->512@4 28.8 -> 18.8 / 26.4 -> 18.2.  DML_TALL_TILES=0 restores the older plans.
-    static const bool tall_ok = [] {
-        const char* e = getenv("DML_TALL_TILES");
-        return !(e && e[0] == '0');
-    }();
+    const bool tall_ok = conv_tall_tiles();
     // (tuning: DML_TALL_VARIANT="v256,v128" picks the kernel variant per tile height)
     static const int v256 = [] { const char* e = getenv("DML_TALL_VARIANT"); return e ? atoi(e) : 0; }();
     static const int v128 = [] {
@@ -614,7 +631,6 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(IgemmArgs p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int C = p.C, hw = p.hw;
     const int chunks = 1 << p.log_chunks;
-    const int steps = 9 * chunks;
     const int halo = hw + 1;
 
     const int lrow = lane >> 3, slot = lane & 7;
@@ -870,9 +886,16 @@ using namespace igemm;
 
 size_t conv3x3_igemm_workspace_elems(ConvShape s) {
     const int M = s.batch * s.hw * s.hw;
-    const Plan pl = choose_plan(s.batch, s.hw, s.cout, s.cin);
-    // room for the widest split so a forced plan (tuning) never outgrows the buffer
-    return pl.splits > 1 ? (size_t)9 * M * s.cout : 0;
+    // under either plan policy (it can change at run time), and room for the widest split so a
+    // forced plan (tuning) never outgrows the buffer
+    const bool was = conv_tall_tiles();
+    bool splits = false;
+    for (bool tall : {true, false}) {
+        set_conv_tall_tiles(tall);
+        splits = splits || choose_plan(s.batch, s.hw, s.cout, s.cin).splits > 1;
+    }
+    set_conv_tall_tiles(was);
+    return splits ? (size_t)9 * M * s.cout : 0;
 }
 
 int conv3x3_igemm_stats_rows(ConvShape s, const int* force_plan) {
