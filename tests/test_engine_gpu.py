@@ -615,3 +615,38 @@ def test_bench_prints_one_json_record():
         assert rec["value"] > 0 and rec["higher_is_better"] is True
         assert abs(rec["value"] - rec["config"]["global_batch"] / (rec["ms_per_step"] / 1e3)) \
             < 0.01 * rec["value"]
+
+
+@pytest.mark.parametrize("batch_norm", [False, True])
+def test_plan_policy_switches_between_steps(batch_norm):
+    """The convolution plan policy (tall patch-resident tiles / streaming tiles only) can change
+    between steps of one engine - bench.py times both on a live multi-rank job: the same steps from
+    one snapshot under either policy agree to bf16 rounding (other tiles, other summation orders),
+    workspaces sized at construction serve both, and the switch is restored."""
+    from distributed_machine_learning_amd.ops import native
+    C = native.lib()
+    was = C.conv_tall_tiles()
+    nb, _ = _mk(batch_norm, batch=256)
+    batches = [_batch(256, seed=s)[1:] for s in range(2)]
+    snap = nb.snapshot()
+    finals, losses = [], []
+    try:
+        for tall in (True, False, True):
+            C.set_conv_tall_tiles(tall)
+            assert C.conv_tall_tiles() is tall
+            for i in range(3):
+                loss = nb.train_step(*batches[i % 2])
+            torch.cuda.synchronize()
+            finals.append(nb.params.clone())
+            losses.append(float(loss.item()))
+            nb.restore(snap)
+    finally:
+        C.set_conv_tall_tiles(was)
+    assert torch.equal(finals[0], finals[2])                 # a policy is bit-reproducible
+    assert not torch.equal(finals[0], finals[1])             # ... and the two really differ
+    assert abs(losses[0] - losses[1]) < 0.02 * max(1.0, abs(losses[0])), losses
+    moved = _rel(finals[0], snap[0])
+    # (measured 0.2 of the three steps' movement under BatchNorm, whose batch statistics amplify the
+    # bf16 rounding differences of the activations as in test_training_steps_track_torch)
+    bound = (0.5 if batch_norm else 0.05) * moved + 1e-5
+    assert _rel(finals[1], finals[0]) < bound, (_rel(finals[1], finals[0]), moved)
