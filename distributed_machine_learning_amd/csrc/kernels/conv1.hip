@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const uint16_t* __rest
 
 // dw[co][tap][c] = sum_blocks slab[b][co][tap*4+c] (c < 3), db[co] = sum_blocks slab[b][co][36].
 // A latency chain, not a bandwidth problem (5 MB): 160 blocks of 16 outputs x 16 parts; a part
-// folds every 16th slab row with eight independent loads in flight, the parts meet in LDS.
+// folds every 16th slab row with up to 32 independent loads in flight, the parts meet in LDS.
 __global__ __launch_bounds__(256) void conv1_wgrad_finish_kernel(const float* __restrict__ slab,
                                                                  float* __restrict__ dw,
                                                                  float* __restrict__ db,
@@ -422,6 +422,15 @@ __global__ __launch_bounds__(256) void conv1_wgrad_finish_kernel(const float* __
     const int o = blockIdx.x * 16 + col;                     // 0 .. 2559 = co * 40 + k
     float s = 0.f;
     int b = part;
+    // (512 slabs at batch 256: one round trip of 32 loads per thread instead of four of eight -
+    // the kernel sits on the tail of backward's critical path)
+    for (; b + 31 * 16 < nblocks; b += 32 * 16) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = slab[(size_t)(b + 16 * u) * 2560 + o];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s += v[u];
+    }
     for (; b + 7 * 16 < nblocks; b += 8 * 16) {
         float v[8];
 #pragma unroll
