@@ -1,7 +1,7 @@
 # 1-GPU numbers of every reference configuration (parts 1 / 2a / 2b / 3) in both precisions,
-# one JSON line each under gpurun_out/baseline_r3/ plus a summary on stdout.
+# one JSON line each under gpurun_out/baseline_table/ plus a summary on stdout.
 set -e
-out=gpurun_out/baseline_r3
+out=gpurun_out/baseline_table
 mkdir -p $out
 for dtype in bf16 fp32; do
   for cfg in "part1" "part2a --force-comm" "part2b --force-comm" "part3" "part3 --force-comm"; do

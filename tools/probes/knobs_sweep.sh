@@ -1,5 +1,5 @@
-# schedule knobs re-measured with the tall conv tiles and the round-3 build flags (one box, back to back)
-out=gpurun_out/knobs_r3; mkdir -p $out
+# schedule knobs re-measured with the tall conv tiles and without packed fp32 pairs (one box, back to back)
+out=gpurun_out/knobs_sweep; mkdir -p $out
 run() { tag=$1; shift; timeout -k 10 120 python bench.py --steps 300 --warmup 20 --windows 2 "$@" 2>>$out/err.log > $out/$tag.json || { echo "$tag failed"; return; }
   python -c "import json,sys; d=json.load(open('$out/$tag.json')); print('%-28s %.4f  median %.4f' % ('$tag', d['ms_per_step'], d['windows']['median_ms_per_step']))"; }
 run base
