@@ -136,9 +136,10 @@ def parse(argv=None):
                     help="cap on RCCL's channels (NCCL_MAX_NCHANNELS, set before the communicator "
                          "exists): fewer channels leave more compute units to backward while the "
                          "buckets are in flight; 0 keeps the library's choice")
-    ap.add_argument("--plan-policy", choices=("auto", "tall", "streaming"), default="auto",
+    ap.add_argument("--plan-policy", choices=("auto", "tall", "tall128", "streaming"), default="auto",
                     help="convolution tile plans of the native bf16 engine: the tall patch-resident "
-                         "tiles (one block per CU, nearly all of its LDS) or the streaming tiles only. "
+                         "tiles (one block per CU, nearly all of its LDS; tall128: no tile taller than 128 "
+                         "pixels, twice the blocks) or the streaming tiles only. "
                          "auto: tall on one GPU; with more than one rank both are timed on the live job "
                          "before the measured region (a communication library's resident blocks can "
                          "push a one-block-per-CU grid into a second round) and the faster one runs")
@@ -377,13 +378,17 @@ def run_rank(ns) -> None:
     if backend.name == "native" and ns.dtype == "bf16":
         from distributed_machine_learning_amd.ops import native as _native
         _C = _native.lib()
+        def set_policy(name):
+            _C.set_conv_tall_tiles(name != "streaming")
+            _C.set_conv_tall_max_rows(128 if name == "tall128" else 256)
+
         if ns.plan_policy != "auto":
-            _C.set_conv_tall_tiles(ns.plan_policy == "tall")
+            set_policy(ns.plan_policy)
             plan_policy = {"chosen": ns.plan_policy, "how": "flag"}
         elif world > 1 and comm is not None:
             tried = {}
-            for name in ("tall", "streaming"):
-                _C.set_conv_tall_tiles(name == "tall")
+            for name in ("tall", "tall128", "streaming"):
+                set_policy(name)
                 for i in range(10):
                     backend.train_step(*batches[i % len(batches)])
                 t_pol, _ = timed(40)
@@ -391,7 +396,7 @@ def run_rank(ns) -> None:
                 times = comm.all_gather_scalars(t_pol, torch.float32)
                 tried[name] = round(float(times.max()) / 40 * 1e3, 4)
             chosen = min(tried, key=tried.get)
-            _C.set_conv_tall_tiles(chosen == "tall")
+            set_policy(chosen)
             plan_policy = {"chosen": chosen, "how": "timed on this job", "ms_per_step": tried}
         else:
             plan_policy = {"chosen": "tall" if _C.conv_tall_tiles() else "streaming", "how": "default"}

@@ -104,6 +104,8 @@ int conv3x3_igemm_stats_rows(ConvShape s, const int* force_plan = nullptr);
 // (default), or streaming tiles only; switchable between steps
 bool conv_tall_tiles();
 void set_conv_tall_tiles(bool on);
+int conv_tall_max_rows();
+void set_conv_tall_max_rows(int rows);       // 256 (default) or 128
 
 
 // First layer: x is [B,32,32,4] bf16 (3 channels + zero pad), w1 is [64][64] bf16 with

@@ -464,6 +464,7 @@ ColReducePlan finish_stats_plan(int M, int N) {
 // persistent blocks can push a 256-block grid into a second round (bench.py measures both policies on
 // the live job when there is more than one rank).
 std::atomic<int> g_tall_tiles{-1};
+std::atomic<int> g_tall_max_rows{256};
 }  // namespace igemm
 bool conv_tall_tiles() {
     int v = igemm::g_tall_tiles.load(std::memory_order_relaxed);
@@ -475,6 +476,13 @@ bool conv_tall_tiles() {
     return v != 0;
 }
 void set_conv_tall_tiles(bool on) { igemm::g_tall_tiles.store(on ? 1 : 0, std::memory_order_relaxed); }
+// tallest tall tile the launcher picks: 256 (default) or 128 pixels - twice the blocks per layer, so
+// a grid loses less when some compute units are not available to it
+int conv_tall_max_rows() { return igemm::g_tall_max_rows.load(std::memory_order_relaxed); }
+void set_conv_tall_max_rows(int rows) {
+    if (rows != 128 && rows != 256) throw std::invalid_argument("set_conv_tall_max_rows: 128 or 256");
+    igemm::g_tall_max_rows.store(rows, std::memory_order_relaxed);
+}
 namespace igemm {
 
 struct Plan {
@@ -519,7 +527,7 @@ Plan choose_plan(int batch, int hw, int N, int cin, const int* force = nullptr) 
         return c ? atoi(c + 1) : 0;
     }();
     if (tall_ok && hw <= 16 && hw >= 2) {
-        if (blocks(256, 64) >= 256) return {256, 64, 1, false, 20 + v256};
+        if (conv_tall_max_rows() >= 256 && blocks(256, 64) >= 256) return {256, 64, 1, false, 20 + v256};
         if (blocks(128, 64) >= 256) return {128, 64, 1, false, 20 + v128};
         // Half a block per CU (256 -> 512 @ 4x4 backward-data): still one block per tile.  Dividing
         // the channel chunks between two blocks per tile (fp32 slabs summed by the consumer, splits =

@@ -198,7 +198,7 @@ def test_bench_self_launches_two_ranks_and_proves_it(mode):
     assert rec["extras_error"] is None
     # both convolution plan policies were timed on this job and the faster one ran
     pol = rec["config"]["plan_policy"]
-    assert pol["how"] == "timed on this job" and set(pol["ms_per_step"]) == {"tall", "streaming"}
+    assert pol["how"] == "timed on this job" and set(pol["ms_per_step"]) == {"tall", "tall128", "streaming"}
     assert pol["chosen"] == min(pol["ms_per_step"], key=pol["ms_per_step"].get)
     # the numerical self-checks of a multi-rank run: against rank 0 alone on the global batch in
     # all three modes, and (bucketed mode) flag words against event pairs bit for bit
