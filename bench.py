@@ -399,7 +399,9 @@ def run_rank(ns) -> None:
             set_policy(chosen)
             plan_policy = {"chosen": chosen, "how": "timed on this job", "ms_per_step": tried}
         else:
-            plan_policy = {"chosen": "tall" if _C.conv_tall_tiles() else "streaming", "how": "default"}
+            now = ("streaming" if not _C.conv_tall_tiles()
+                   else "tall128" if _C.conv_tall_max_rows() == 128 else "tall")
+            plan_policy = {"chosen": now, "how": "default"}
 
     if ns.prime_steps > 0 and hasattr(backend, "prime"):
         backend.prime(batches, ns.prime_steps)

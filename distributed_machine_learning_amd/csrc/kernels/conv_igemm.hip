@@ -464,7 +464,7 @@ ColReducePlan finish_stats_plan(int M, int N) {
 // persistent blocks can push a 256-block grid into a second round (bench.py measures both policies on
 // the live job when there is more than one rank).
 std::atomic<int> g_tall_tiles{-1};
-std::atomic<int> g_tall_max_rows{256};
+std::atomic<int> g_tall_max_rows{-1};        // (-1: DML_TALL_MAX_ROWS, else 256)
 }  // namespace igemm
 bool conv_tall_tiles() {
     int v = igemm::g_tall_tiles.load(std::memory_order_relaxed);
@@ -478,7 +478,15 @@ bool conv_tall_tiles() {
 void set_conv_tall_tiles(bool on) { igemm::g_tall_tiles.store(on ? 1 : 0, std::memory_order_relaxed); }
 // tallest tall tile the launcher picks: 256 (default) or 128 pixels - twice the blocks per layer, so
 // a grid loses less when some compute units are not available to it
-int conv_tall_max_rows() { return igemm::g_tall_max_rows.load(std::memory_order_relaxed); }
+int conv_tall_max_rows() {
+    int v = igemm::g_tall_max_rows.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("DML_TALL_MAX_ROWS");
+        v = (e && atoi(e) == 128) ? 128 : 256;
+        igemm::g_tall_max_rows.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 void set_conv_tall_max_rows(int rows) {
     if (rows != 128 && rows != 256) throw std::invalid_argument("set_conv_tall_max_rows: 128 or 256");
     igemm::g_tall_max_rows.store(rows, std::memory_order_relaxed);
